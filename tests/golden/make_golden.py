@@ -1,0 +1,343 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: imports the UNMODIFIED reference (tomerraviv95/meta-viterbinet,
+mounted read-only at /root/reference) on CPU and writes small input/output fixtures to
+tests/golden/*.npz.  Run in the build container only:
+
+    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python tests/golden/make_golden.py
+
+The reference never travels to the GPU box; the .npz files (data only: inputs, weights as raw
+arrays, expected outputs) do.  Fixture ids follow SURVEY.md section 8c (G1..G7).
+"""
+import os
+import sys
+import tempfile
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+REF = os.environ.get("MVN_REFERENCE", "/root/reference")
+if REF not in sys.path:
+    sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TMP = tempfile.mkdtemp(prefix="mvn_golden_")
+
+from python_code.utils.trellis_utils import create_transition_table, acs_block, calculate_states  # noqa: E402
+from python_code.utils.metrics import calculate_error_rates  # noqa: E402
+from python_code.detectors.VA.va_detector import VADetector  # noqa: E402
+from python_code.detectors.VNET.vnet_detector import VNETDetector  # noqa: E402
+from python_code.detectors.META_VNET.meta_vnet_detector import META_VNETDetector  # noqa: E402
+import python_code.channel.channel_estimation as chest  # noqa: E402
+from python_code.trainers.VA.va_trainer import VATrainer  # noqa: E402
+from python_code.trainers.VNET.vnet_trainer import VNETTrainer  # noqa: E402
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}  ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+def patch_cost2100():
+    """the loader wants combined_h_{i}.mat, the repo ships h_{i}.mat."""
+    d = os.path.join(TMP, "cost2100")
+    os.makedirs(d, exist_ok=True)
+    for i in range(4):
+        dst = os.path.join(d, f"combined_h_{i}.mat")
+        if not os.path.exists(dst):
+            os.symlink(os.path.join(REF, "resources", "cost2100_channel", f"h_{i}.mat"), dst)
+    chest.COST2100_DIR = d
+
+
+# ----------------------------------------------------------------------------- G1
+def g1_acs():
+    out = {}
+    rng = np.random.RandomState(11)
+    for S in (2, 4, 8, 16, 256):
+        table = create_transition_table(S)
+        out[f"table_S{S}"] = table.astype(np.int64)
+        tt = torch.Tensor(table)
+        for B in (1, 3, 64):
+            ip = rng.normal(0, 3, (B, S)).astype(np.float32)
+            c = rng.normal(0, 3, (B, S)).astype(np.float32)
+            if B == 3:  # force exact ties and a few repeated values
+                ip[1] = 0.0
+                c[1] = 1.5
+                c[2, ::2] = c[2, 1::2]
+                ip[2, ::2] = ip[2, 1::2]
+            v, j = acs_block(torch.tensor(ip), torch.tensor(c), tt, S)
+            out[f"in_S{S}_B{B}"] = ip
+            out[f"llr_S{S}_B{B}"] = c
+            out[f"out_S{S}_B{B}"] = v.numpy()
+            out[f"argj_S{S}_B{B}"] = j.numpy()
+    save("g1_acs_block", **out)
+
+
+# ----------------------------------------------------------------------------- G2
+def hand_step_va(det, y, phase, snr, gamma, count=None):
+    """Re-run VADetector.forward's own statements to expose costs and final metrics."""
+    in_prob = torch.zeros([y.shape[0], det.n_states])
+    priors = det.compute_likelihood_priors(y, snr, gamma, phase, count)
+    dec = torch.zeros(y.shape)
+    for i in range(det.transmission_length):
+        dec[:, i] = torch.argmin(in_prob, dim=1) % 2
+        in_prob, _ = acs_block(in_prob, priors[:, i], det.transition_table, det.n_states)
+    return priors, dec, in_prob
+
+
+def g2_va():
+    cases = [
+        # name, L, frames, subframes, T, snr, coeffs, fading_ch, fading_dec, taps_type
+        ("L4_static", 4, 1, 25, 256, 10, "time_decay", False, False, 1),
+        ("L4_fading1", 4, 1, 25, 256, 10, "time_decay", True, True, 1),
+        ("L4_fading2", 4, 2, 10, 128, 7, "time_decay", True, True, 2),
+        ("L4_cost2100", 4, 1, 25, 136, 12, "cost2100", False, False, 1),
+        ("L2_static", 2, 1, 12, 96, 10, "time_decay", False, False, 1),
+        ("L3_static", 3, 1, 12, 96, 8, "time_decay", False, False, 1),
+        ("L8_static", 8, 1, 4, 128, 10, "time_decay", False, False, 1),
+        ("L4_config1", 4, 4, 25, 1000, 10, "time_decay", False, False, 1),
+    ]
+    out = {}
+    names = []
+    for (name, L, frames, sub, T, snr, coef, fch, fdec, ttype) in cases:
+        tr = VATrainer(use_ecc=False, memory_length=L, val_block_length=T, val_frames=frames,
+                       subframes_in_frame=sub, channel_coefficients=coef, fading_in_channel=fch,
+                       fading_in_decoder=fdec, fading_taps_type=ttype, noisy_est_var=0,
+                       val_SNR_start=snr, val_SNR_end=snr, gamma=0.2, weights_dir=TMP,
+                       noise_seed=3450002, word_seed=7860002)
+        tx, rx = tr.channel_dataset["val"].__getitem__(snr_list=[snr], gamma=0.2)
+        det = tr.detector
+        with torch.no_grad():
+            dec = det(rx, "val", snr, 0.2)
+            cost, dec2, final = hand_step_va(det, rx, "val", snr, 0.2)
+        assert torch.equal(dec, dec2)
+        W = frames * sub
+        h = np.concatenate([chest.estimate_channel(L, 0.2, noisy_est_var=0, fading=fdec, index=i,
+                                                   fading_taps_type=ttype, channel_coefficients=coef)
+                            for i in range(W)], axis=0)
+        priors = det.compute_state_priors(h).numpy()  # [S, W]
+        ser, fer, err_idx = calculate_error_rates(dec[tr.data_indices], tx[tr.data_indices])
+        ser_all, fer_all, _ = calculate_error_rates(dec, tx)
+        names.append(name)
+        big = name == "L4_config1"
+        out[f"{name}_meta"] = np.array([L, frames, sub, T, snr, int(fdec), ttype], np.int64)
+        out[f"{name}_coef"] = np.array(coef)
+        out[f"{name}_tx"] = tx.numpy().astype(np.uint8)
+        out[f"{name}_rx"] = rx.numpy()
+        out[f"{name}_h"] = h
+        out[f"{name}_state_priors"] = priors
+        out[f"{name}_cost_head"] = cost[: (2 if big else 4), :8].numpy()
+        out[f"{name}_decoded"] = dec.numpy().astype(np.uint8)
+        out[f"{name}_final"] = final.numpy()
+        out[f"{name}_data_indices"] = tr.data_indices.numpy()
+        out[f"{name}_rates"] = np.array([ser, fer, ser_all, fer_all], np.float64)
+        out[f"{name}_err_idx"] = err_idx.numpy()
+        # by-word call (count given): one word, its own channel row (trainer.py:295)
+        if name in ("L4_fading1", "L4_cost2100"):
+            cnt = 7
+            with torch.no_grad():
+                dw = det(rx[cnt].reshape(1, -1), "val", snr, 0.2, cnt)
+            out[f"{name}_count{cnt}_decoded"] = dw.numpy().astype(np.uint8)
+        print(name, "ser", ser, "fer", fer)
+    out["names"] = np.array(names)
+    save("g2_va", **out)
+
+
+# ----------------------------------------------------------------------------- G3/G4
+def export_weights(det):
+    return [p.detach().numpy().copy() for p in det.parameters()]
+
+
+def train_vnet(L, snr):
+    """Briefly train the reference ViterbiNet with the reference's own trainer (unseeded
+    internals, SURVEY 8c caveat): only the resulting weights are kept, as raw arrays."""
+    torch.manual_seed(1234)
+    tr = VNETTrainer(use_ecc=False, memory_length=L, val_block_length=120, val_frames=1,
+                     subframes_in_frame=25, train_block_length=120, train_frames=4,
+                     train_minibatch_num=12, channel_coefficients="time_decay",
+                     fading_in_channel=False, fading_in_decoder=False, noisy_est_var=0,
+                     train_SNR_start=snr, train_SNR_end=snr, val_SNR_start=snr, val_SNR_end=snr,
+                     gamma=0.2, weights_dir=os.path.join(TMP, f"w_L{L}"), self_supervised=False,
+                     online_meta=False, eval_mode="aggregated", noise_seed=3450002, word_seed=7860002)
+    os.makedirs(tr.weights_dir, exist_ok=True)
+    tr.train()
+    ck = torch.load(os.path.join(tr.weights_dir, f"snr_{snr}_gamma_0.2.pt"))
+    tr.detector.load_state_dict(ck["model_state_dict"])
+    return tr
+
+
+def margins(logits, T):
+    """per-(b,t) gap between the two smallest DISTINCT path metrics before stage t."""
+    B, _, S = logits.shape
+    inp = torch.zeros(B, S)
+    tt = torch.Tensor(create_transition_table(S))
+    out = np.zeros((B, T), np.float32)
+    for i in range(T):
+        u = torch.sort(inp[:, : max(S // 2, 1)], dim=1).values if i > 0 else inp
+        out[:, i] = (u[:, 1] - u[:, 0]).numpy() if u.shape[1] > 1 else 0
+        inp, _ = acs_block(inp, -torch.tensor(logits[:, i]), tt, S)
+    return out
+
+
+def g3_g4_vnet():
+    out = {}
+    names = []
+    torch.set_num_threads(1)
+    trained = {}
+    for L in (4, 2):
+        trained[L] = train_vnet(L, 10)
+    cases = [
+        # name, S, B, T, weights-source, threads
+        ("S16_init_exact", 16, 8, 64, "init", 1),
+        ("S16_trained_exact", 16, 25, 120, "trained", 1),
+        ("S16_trained_mt", 16, 25, 120, "trained", 8),
+        ("S16_trained_odd", 16, 7, 45, "trained", 8),
+        ("S4_trained_exact", 4, 8, 120, "trained", 1),
+        ("S256_init_exact", 256, 2, 64, "init", 1),
+        ("S2_init_exact", 2, 4, 32, "init", 1),
+    ]
+    for (name, S, B, T, src, nthreads) in cases:
+        L = int(np.log2(S))
+        torch.set_num_threads(nthreads)
+        if src == "trained":
+            tr = trained[L]
+            det = VNETDetector(S, {"train": T, "val": T})
+            det.load_state_dict(tr.detector.state_dict())
+            # fresh channel draw through the reference's generator at this size
+            t2 = VNETTrainer(use_ecc=False, memory_length=L, val_block_length=T, val_frames=1,
+                             subframes_in_frame=B, channel_coefficients="time_decay",
+                             fading_in_channel=False, fading_in_decoder=False, noisy_est_var=0,
+                             val_SNR_start=10, val_SNR_end=10, gamma=0.2, weights_dir=TMP,
+                             noise_seed=3450002, word_seed=7860002)
+            tx, y = t2.channel_dataset["val"].__getitem__(snr_list=[10], gamma=0.2)
+        else:
+            torch.manual_seed(100 + S)
+            det = VNETDetector(S, {"train": T, "val": T})
+            g = torch.Generator().manual_seed(7 + S)
+            y = torch.randn(B, T, generator=g) * 1.5
+            tx = torch.zeros(B, T)
+        with torch.no_grad():
+            logits = det(y, "train")
+            dec = det(y, "val")
+            meta = META_VNETDetector(S, {"train": T, "val": T})
+            var = list(det.parameters())
+            dec_meta = meta(y, "val", var)
+            logits_meta = meta(y, "train", var)
+        W = export_weights(det)
+        names.append(name)
+        out[f"{name}_meta"] = np.array([S, B, T, nthreads], np.int64)
+        for i, w in enumerate(W):
+            out[f"{name}_w{i}"] = w
+        out[f"{name}_y"] = y.numpy()
+        out[f"{name}_tx"] = tx.numpy().astype(np.uint8)
+        out[f"{name}_logits"] = logits.numpy()
+        out[f"{name}_decoded"] = dec.numpy().astype(np.uint8)
+        out[f"{name}_margin"] = margins(logits.numpy(), T)
+        out[f"{name}_meta_equal"] = np.array([bool(torch.equal(dec, dec_meta)),
+                                              bool(torch.equal(logits, logits_meta))])
+        print(name, "meta==vnet", out[f"{name}_meta_equal"], "state_dict", list(det.state_dict().keys()))
+    out["names"] = np.array(names)
+    out["state_dict_keys"] = np.array(list(det.state_dict().keys()))
+    torch.set_num_threads(1)
+    save("g3_vnet", **out)
+    return trained[4]
+
+
+# ----------------------------------------------------------------------------- G5
+def g5_kats():
+    out = {}
+    out["states_kat_in"] = np.array([[1, 0, 1, 1, 0, 0, 1]], np.float32)
+    out["states_kat_out"] = calculate_states(4, torch.tensor(out["states_kat_in"])).numpy()
+    rng = np.random.RandomState(5)
+    for L in (2, 3, 4, 8):
+        w = rng.randint(0, 2, (3, 40)).astype(np.float32)
+        out[f"states_L{L}_in"] = w
+        out[f"states_L{L}_out"] = calculate_states(L, torch.tensor(w)).numpy()
+    pred = rng.randint(0, 2, (12, 30)).astype(np.float32)
+    tgt = pred.copy()
+    tgt[2, 5] = 1 - tgt[2, 5]
+    tgt[2, 9] = 1 - tgt[2, 9]
+    tgt[7, 0] = 1 - tgt[7, 0]
+    tgt[11] = 1 - tgt[11]
+    ser, fer, idx = calculate_error_rates(torch.tensor(pred), torch.tensor(tgt))
+    out["er_pred"], out["er_tgt"] = pred, tgt
+    out["er_rates"] = np.array([ser, fer], np.float64)
+    out["er_idx"] = idx.numpy()
+    ser0, fer0, idx0 = calculate_error_rates(torch.tensor(pred), torch.tensor(pred))
+    out["er_rates_clean"] = np.array([ser0, fer0], np.float64)
+    save("g5_kats", **out)
+
+
+# ----------------------------------------------------------------------------- G6
+def g6_channels():
+    out = {}
+    out["cost2100"] = np.concatenate([chest.estimate_channel(4, 0.2, "cost2100", index=i) for i in range(300)])
+    for ttype in (1, 2):
+        out[f"time_decay_fading{ttype}"] = np.concatenate(
+            [chest.estimate_channel(4, 0.2, "time_decay", fading=True, index=i, fading_taps_type=ttype)
+             for i in range(300)])
+    for L in (2, 3, 4, 8):
+        out[f"time_decay_L{L}"] = chest.estimate_channel(L, 0.2, "time_decay")
+    out["time_decay_gamma05"] = chest.estimate_channel(4, 0.5, "time_decay")
+    save("g6_channels", **out)
+
+
+# ----------------------------------------------------------------------------- G7
+def g7_by_word(trained):
+    """eval_by_word without online updates ("joint" variant): deterministic given weights."""
+    wdir = os.path.join(TMP, "w_byword")
+    os.makedirs(wdir, exist_ok=True)
+    torch.save({"model_state_dict": trained.detector.state_dict(), "optimizer_state_dict": {}, "loss": 0.0},
+               os.path.join(wdir, "snr_10_gamma_0.2.pt"))
+    out = {}
+    for coef in ("time_decay", "cost2100"):
+        tr = VNETTrainer(eval_mode="by_word", use_ecc=True, n_symbols=2, memory_length=4,
+                         val_block_length=120, val_frames=12, subframes_in_frame=25,
+                         channel_coefficients=coef, fading_in_channel=(coef == "time_decay"),
+                         fading_in_decoder=False, fading_taps_type=2, noisy_est_var=0,
+                         self_supervised=False, online_meta=False, val_SNR_start=10, val_SNR_end=10,
+                         gamma=0.2, weights_dir=wdir, noise_seed=3450002, word_seed=7860002)
+        rec = {"y": [], "dec": [], "count": []}
+        orig_forward = tr.detector.forward
+
+        def spy(y, phase, snr=None, gamma=None, count=None, _f=orig_forward):
+            r = _f(y, phase, snr, gamma, count)
+            if phase == "val":
+                rec["y"].append(y.detach().numpy().copy())
+                rec["dec"].append(r.detach().numpy().copy())
+                rec["count"].append(-1 if count is None else count)
+            return r
+
+        tr.detector.forward = spy
+        ser_by_word = tr.evaluate()
+        out[f"{coef}_ser_by_word"] = np.asarray(ser_by_word, np.float64)
+        out[f"{coef}_y"] = np.concatenate(rec["y"]).astype(np.float32)
+        out[f"{coef}_detected"] = np.concatenate(rec["dec"]).astype(np.uint8)
+        out[f"{coef}_count"] = np.array(rec["count"], np.int64)
+        out[f"{coef}_data_indices"] = tr.data_indices.numpy()
+        print(coef, "mean ser_by_word", float(np.mean(ser_by_word)), "blocks", len(rec["y"]))
+    for i, w in enumerate(export_weights(trained.detector)):
+        out[f"w{i}"] = w
+    save("g7_by_word", **out)
+
+
+if __name__ == "__main__":
+    import contextlib
+    import io
+
+    patch_cost2100()
+    g1_acs()
+    g5_kats()
+    g6_channels()
+    g2_va()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):  # the reference trainers print per-step progress
+        trained4 = g3_g4_vnet()
+    print("\n".join(l for l in buf.getvalue().splitlines() if l.startswith(("S", "wrote", "best"))))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        g7_by_word(trained4)
+    print("\n".join(l for l in buf.getvalue().splitlines() if l.startswith(("time_decay", "cost2100", "wrote", "Final"))))
+    print("torch", torch.__version__, "numpy", np.__version__)

@@ -1,0 +1,145 @@
+"""Pins the CPU oracle (oracle/mvn_oracle.c) against golden vectors captured from the reference
+(tests/golden/make_golden.py).  CPU only.  Bit-exact unless a tolerance is written in the test."""
+import numpy as np
+import pytest
+
+
+# ---- a1/a2: transition table + one ACS stage (trellis_utils.py:7-30) ----------------------
+@pytest.mark.parametrize("S", [2, 4, 8, 16, 256])
+def test_transition_table(golden, oracle, S):
+    g = golden("g1_acs_block")
+    assert np.array_equal(oracle.create_transition_table(S), g[f"table_S{S}"])
+
+
+@pytest.mark.parametrize("S", [2, 4, 8, 16, 256])
+@pytest.mark.parametrize("B", [1, 3, 64])
+def test_acs_block(golden, oracle, S, B):
+    g = golden("g1_acs_block")
+    out, j = oracle.acs_block(g[f"in_S{S}_B{B}"], g[f"llr_S{S}_B{B}"])
+    assert np.array_equal(out, g[f"out_S{S}_B{B}"])
+    assert np.array_equal(j, g[f"argj_S{S}_B{B}"])
+
+
+# ---- a3-a5, a10: VA detector (va_detector.py:42-98) ---------------------------------------
+def _va_names(golden):
+    return [str(n) for n in golden("g2_va")["names"]]
+
+
+def test_va_cases_present(golden):
+    assert len(_va_names(golden)) == 8
+
+
+@pytest.mark.parametrize("name", ["L4_static", "L4_fading1", "L4_fading2", "L4_cost2100", "L2_static",
+                                  "L3_static", "L8_static", "L4_config1"])
+def test_va_decode_bit_exact(golden, oracle, name):
+    g = golden("g2_va")
+    priors = np.ascontiguousarray(g[f"{name}_state_priors"].T)  # [W,S]
+    y = g[f"{name}_rx"]
+    head = g[f"{name}_cost_head"]
+    cost = oracle.va_costs(y[: head.shape[0]], priors[: head.shape[0]], T=8)
+    assert np.array_equal(cost, head)  # va_detector.py:64-68, 4 separately rounded ops
+    dec, final = oracle.va_decode(y, priors)
+    assert np.array_equal(dec, g[f"{name}_decoded"].astype(np.float32))
+    assert np.array_equal(final, g[f"{name}_final"])
+    assert np.all(dec[:, 0] == 0)  # quirk Q1
+    # sweep over materialised costs gives the same thing
+    dec2, final2 = oracle.acs_sweep(oracle.va_costs(y, priors))
+    assert np.array_equal(dec2, dec) and np.array_equal(final2, final)
+    # metrics.py:7-17 on data rows (trainer.py:238)
+    rows = g[f"{name}_data_indices"]
+    tx = g[f"{name}_tx"].astype(np.float32)
+    ser, fer = oracle.error_rates(oracle.count_errors(dec, tx, rows))
+    # the reference takes an fp32 mean; the integer ratio differs by <= 1e-7 relative + fp32 eps
+    assert ser == pytest.approx(g[f"{name}_rates"][0], rel=1e-6, abs=1e-7)
+    assert fer == pytest.approx(g[f"{name}_rates"][1], rel=1e-6, abs=1e-7)
+
+
+@pytest.mark.parametrize("name", ["L4_fading1", "L4_cost2100"])
+def test_va_by_word_count(golden, oracle, name):
+    g = golden("g2_va")
+    cnt = 7
+    priors = np.ascontiguousarray(g[f"{name}_state_priors"].T)[cnt: cnt + 1]
+    dec = oracle.va_decode(g[f"{name}_rx"][cnt: cnt + 1], priors, want_final=False)
+    assert np.array_equal(dec, g[f"{name}_count{cnt}_decoded"].astype(np.float32))
+
+
+# ---- a6-a8: ViterbiNet / Meta-ViterbiNet (vnet_detector.py:35-63) -------------------------
+VNET_EXACT = ["S16_init_exact", "S16_trained_exact", "S4_trained_exact", "S256_init_exact", "S2_init_exact"]
+VNET_TAIL = ["S16_trained_mt", "S16_trained_odd"]
+
+
+def _weights(g, name):
+    return [g[f"{name}_w{i}"] for i in range(6)]
+
+
+@pytest.mark.parametrize("name", VNET_EXACT)
+def test_vnet_bit_exact(golden, oracle, name):
+    """torch single-threaded, B*T*100 a multiple of 32: every activation goes through ATen's
+    vectorised sigmoid, and the oracle reproduces logits AND decisions bit for bit."""
+    g = golden("g3_vnet")
+    y = g[f"{name}_y"]
+    dec, logits = oracle.vnet_decode(y, _weights(g, name), want_logits=True)
+    assert np.array_equal(logits, g[f"{name}_logits"])
+    assert np.array_equal(dec, g[f"{name}_decoded"].astype(np.float32))
+    assert np.array_equal(oracle.vnet_logits(y, _weights(g, name)), g[f"{name}_logits"])
+    assert g[f"{name}_meta_equal"].all()  # a8: META_VNET(var=parameters()) == VNET in the reference
+
+
+@pytest.mark.parametrize("name", VNET_TAIL)
+def test_vnet_scalar_tail_tolerance(golden, oracle, name):
+    """8 torch threads / ragged sizes: <32 activations per thread chunk take ATen's scalar libm
+    path (1 ulp of the sigmoid).  Tolerance: |dlogit| <= 2e-6 on <= 0.1 % of the logits;
+    decisions still identical."""
+    g = golden("g3_vnet")
+    dec, logits = oracle.vnet_decode(g[f"{name}_y"], _weights(g, name), want_logits=True)
+    ref = g[f"{name}_logits"]
+    assert np.max(np.abs(logits - ref)) <= 2e-6
+    assert np.count_nonzero(logits != ref) <= 1e-3 * ref.size
+    assert np.array_equal(dec, g[f"{name}_decoded"].astype(np.float32))
+
+
+def test_vnet_state_dict_keys(golden):
+    keys = [str(k) for k in golden("g3_vnet")["state_dict_keys"]]
+    assert keys == ["net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias"]
+
+
+# ---- a9/a10 KATs ---------------------------------------------------------------------------
+def test_calculate_states(golden, oracle):
+    g = golden("g5_kats")
+    assert oracle.calculate_states(4, g["states_kat_in"]).tolist() == [13, 6, 3, 9, 4, 2, 1]
+    for L in (2, 3, 4, 8):
+        assert np.array_equal(oracle.calculate_states(L, g[f"states_L{L}_in"]), g[f"states_L{L}_out"])
+
+
+def test_error_rates(golden, oracle):
+    g = golden("g5_kats")
+    c = oracle.count_errors(g["er_pred"], g["er_tgt"])
+    assert c.tolist() == [2 + 1 + 30, 12 * 30, 3, 12]
+    ser, fer = oracle.error_rates(c)
+    assert ser == pytest.approx(g["er_rates"][0], rel=1e-6)
+    assert fer == pytest.approx(g["er_rates"][1], rel=1e-6)
+    assert oracle.error_rates(oracle.count_errors(g["er_pred"], g["er_pred"])) == (0.0, 0.0)
+
+
+# ---- a12: by-word detector calls (trainer.py:295), B=1, T=136 ------------------------------
+@pytest.mark.parametrize("coef", ["time_decay", "cost2100"])
+def test_by_word_detected(golden, oracle, coef):
+    g = golden("g7_by_word")
+    W = [g[f"w{i}"] for i in range(6)]
+    y = g[f"{coef}_y"]  # [300,136], one detector call per row in the reference
+    assert y.shape == (300, 136)
+    dec = oracle.vnet_decode(y, W)
+    ref = g[f"{coef}_detected"].astype(np.float32)
+    # N = 136 symbols per call: 13600 activations = 425 full vectors, no scalar tail -> bit-exact
+    assert np.array_equal(dec, ref)
+
+
+# ---- sigmoid restatement sanity (no golden: property checks) --------------------------------
+def test_sigmoid_special_values(oracle):
+    x = np.array([0.0, -0.0, 88.0, 104.0, 1e10, -88.0, -100.0, -104.5, -1e10, np.inf, -np.inf], np.float32)
+    s = oracle.sigmoid(x)
+    assert s[0] == 0.5 and s[1] == 0.5
+    assert np.all(s[2:5] == 1.0) and s[9] == 1.0
+    assert s[5] == np.float32(6.054601e-39)  # denormal result survives (torch CPU gives the same)
+    assert np.all(s[6:9] == 0.0) and s[10] == 0.0
+    assert np.isnan(oracle.sigmoid(np.array([np.nan], np.float32))[0])
