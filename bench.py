@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- decoded symbols/sec of the ViterbiNet 'val' hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of VNETDetector.forward(y,'val') + on-device error counting over this rank's batch of
+synthetic words (BASELINE.json configs[1]: ViterbiNet L=4, 10 000 blocks x 1000 symbols per GPU, inputs
+resident in HBM).  Blocks are independent: every rank owns its own 10 000 blocks (weak scaling) and the only
+collective is one all-reduce of the int64[4] error counters at the end.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import meta_viterbinet_amd as mvn  # noqa: E402
+
+L, S, T = 4, 16, 1000
+SNR_DB, GAMMA = 10.0, 0.2
+FLOP_PER_SYMBOL = 12.0e3  # 2*(100 + 100*50 + 50*16) + biases/activations + ACS
+ACS_BYTES_PER_SYMBOL = 68.0  # 16 fp32 costs read + 1 fp32 decision written
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def golden_weights(device):
+    """Briefly trained ViterbiNet weights (raw arrays captured from the reference, tests/golden)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g7_by_word.npz"))
+    return [torch.tensor(g[f"w{i}"], device=device) for i in range(6)]
+
+
+def event_time_ms(fn, iters, stream_device):
+    """Average duration of fn() measured with HIP events on the stream the kernels are launched on
+    (the ABI is called with torch's current stream, so torch.cuda.Event brackets exactly those launches)."""
+    start = torch.cuda.Event(enable_timing=True)
+    stop = torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize(stream_device)
+    start.record()
+    for _ in range(iters):
+        fn()
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) / iters
+
+
+def cpu_baseline(weights_np, seed):
+    """The CPU oracle (a port of the reference's algorithm, oracle/mvn_oracle.c) on a bounded sample of the
+    same workload, all host cores.  Reported baseline only -- never part of `value`."""
+    import oracle
+
+    oracle.build()
+    _, y = mvn.synthetic_words(64, T, L, SNR_DB, GAMMA, "cpu", seed=seed)
+    y = y.numpy()
+    t0 = time.perf_counter()
+    oracle.vnet_decode(y, weights_np)
+    dt = time.perf_counter() - t0
+    blocks = int(min(4096, max(64, 15.0 / max(dt / 64, 1e-9))))  # ~15 s of CPU work
+    _, y = mvn.synthetic_words(blocks, T, L, SNR_DB, GAMMA, "cpu", seed=seed)
+    y = y.numpy()
+    t0 = time.perf_counter()
+    oracle.vnet_decode(y, weights_np)
+    dt = time.perf_counter() - t0
+    return {"value": blocks * T / dt, "unit": "symbols/s", "cores": oracle.max_threads(), "kind": "port",
+            "sample": f"oracle.vnet_decode on {blocks} blocks x {T} symbols (same generator/weights), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=10000, help="blocks per GPU (BASELINE configs[1]: 10000)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B = args.blocks
+    weights = golden_weights(dev)
+    det = mvn.VNETDetector(S, {"train": T, "val": T}).to(dev)
+    with torch.no_grad():
+        for p, w in zip(det.parameters(), weights):
+            p.copy_(w)
+    tx, y = mvn.synthetic_words(B, T, L, SNR_DB, GAMMA, dev, seed=3450002 + rank)
+    counters = torch.zeros(4, dtype=torch.int64, device=dev)
+
+    def step():
+        dec = det(y, "val", SNR_DB, GAMMA)
+        mvn.count_errors(dec, tx, None, counters)
+
+    for _ in range(args.warmup):
+        step()
+    counters.zero_()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.all_reduce(counters)  # the single collective: int64[4] error counters over RCCL/xGMI
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    total_symbols = float(world) * B * T * args.steps
+    ser, fer = mvn.rates_from_counters(counters)
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel, timed alone with HIP events on its launch stream
+        lib = mvn._lib.load()
+        st = mvn._lib.current_stream(dev)
+        wp = [mvn._lib.ptr(w) for w in weights]
+        logits = torch.empty(B * T, S, device=dev)
+        yflat = y.reshape(-1)
+        ms_mlp = event_time_ms(lambda: lib.mvn_vnet_logits_f32(mvn._lib.ptr(yflat), *wp, mvn._lib.ptr(logits), B * T, S, st),
+                               5, dev)
+        dec = torch.zeros(B, T, device=dev)
+        ms_acs = event_time_ms(lambda: lib.mvn_acs_sweep_f32(mvn._lib.ptr(logits), mvn._lib.ptr(dec), T, None, B, T, S, st),
+                               5, dev)
+        ms_step = event_time_ms(step, 3, dev)
+        del logits
+        mlp_tflops = FLOP_PER_SYMBOL * B * T / (ms_mlp * 1e-3) / 1e12
+        acs_gbps = ACS_BYTES_PER_SYMBOL * B * T / (ms_acs * 1e-3) / 1e9
+        out = {
+            "metric": "decoded symbols/sec, ViterbiNet L=4 ISI (16 states)",
+            "value": total_symbols / elapsed,
+            "unit": "symbols/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"ViterbiNet L=4, {B} blocks x {T} symbols per GPU (BASELINE configs[1])",
+                       "blocks_per_gpu": B, "block_length": T, "n_states": S, "snr_db": SNR_DB,
+                       "weights": "tests/golden/g7_by_word.npz (trained on the reference)",
+                       "parallelism": f"block-sharded x{world}, one all-reduce of int64[4] counters"},
+            "ser_at_snr": ser,
+            "fer_at_snr": fer,
+            "roofline": {"kernel": "mlp_kernel<1> (ViterbiNet MLP, f32 MFMA 16x16x4)", "bound": "mfma",
+                         "achieved": mlp_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": mlp_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "ms_per_launch": ms_mlp, "flop_per_symbol": FLOP_PER_SYMBOL},
+            "roofline_acs_sweep": {"kernel": "sweep_kernel<16,COST> (mvn_acs_sweep_f32)", "bound": "hbm",
+                                   "achieved": acs_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                   "frac": acs_gbps / PEAK_HBM_GBPS, "traffic": None, "ms_per_launch": ms_acs,
+                                   "bytes_per_symbol": ACS_BYTES_PER_SYMBOL},
+            "ms_per_step_events": ms_step,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline([w.cpu().numpy() for w in weights], 3450002)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

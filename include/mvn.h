@@ -1,0 +1,120 @@
+/*
+ * mvn.h -- C ABI of libmvn_hip.so: the MI355X (gfx950) Viterbi / ViterbiNet detection engine.
+ *
+ * This is the drop-in boundary for the 'val' hot path of tomerraviv95/meta-viterbinet.
+ * The reference has no FFI of its own (pure Python); each entry point below
+ * replaces the body of one reference function and is what a ctypes stub in the reference's
+ * detector modules would bind (INTEGRATION.md shows that stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated otherwise; the caller owns all memory;
+ *   - fp32 row-major; `*_ld` = row stride in elements; S = n_states = 2**memory_length,
+ *     a power of two in [2,256] (the reference's np.uint8 bound, va_detector.py:43);
+ *   - calls enqueue work on `stream` (a hipStream_t; NULL = default stream) and return
+ *     immediately: they never allocate, free or synchronise, so they can be graph-captured;
+ *   - return value: 0 = ok, <0 = bad argument (MVN_E_*), >0 = hipError_t of the failed launch.
+ *   - decisions are written as fp32 {0.,1.} like the reference's decoded_word
+ *     (va_detector.py:90-93); columns >= T of `dec` are not touched (caller zero-fills).
+ *   - arithmetic is IEEE fp32 with one rounding per reference operation; results are
+ *     bit-identical to oracle/mvn_oracle.c for finite inputs (NaN inputs: unspecified).
+ */
+#ifndef MVN_H_
+#define MVN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *mvn_stream_t; /* hipStream_t */
+
+#define MVN_OK 0
+#define MVN_E_DIMS (-1)      /* negative size, T > ld, ... */
+#define MVN_E_STATES (-2)    /* S not a power of two in [2,256] */
+#define MVN_E_PRIORS (-3)    /* Bp < 1 or B % Bp != 0 */
+#define MVN_E_NULL (-4)      /* required pointer is NULL */
+#define MVN_E_WORKSPACE (-5) /* workspace too small for one block */
+#define MVN_E_DEVICE (-6)    /* current device is not gfx950 */
+
+#define MVN_ABI_VERSION 1
+
+/* ABI version of the loaded library (== MVN_ABI_VERSION). */
+int mvn_version(void);
+
+/* Static message for a return code of this library (never NULL). */
+const char *mvn_strerror(int code);
+
+/* 0 if the current HIP device is a gfx950 part; fills optional outputs. Host pointers. */
+int mvn_device_info(int *n_cu, int *lds_bytes_per_cu, char *arch_name, int arch_name_len);
+
+/*
+ * One ACS stage, acs_block of python_code/utils/trellis_utils.py:16-30:
+ *   out[b,s] = min_j (in_prob+llrs)[b,(2s+j)%S];  argmin_j[b,s] in {0,1} (int64, first minimum wins,
+ *   like torch.min(dim=2)); argmin_j may be NULL.  in_prob, llrs, out: [B,S] contiguous.
+ */
+int mvn_acs_block_f32(const float *in_prob, const float *llrs, float *out, int64_t *argmin_j,
+                      int64_t B, int32_t S, mvn_stream_t stream);
+
+/*
+ * ACS sweep over materialised branch costs: the T-step loop
+ *     dec[:,i] = argmin(in_prob,1) % 2 ; in_prob = acs_block(in_prob, cost[:,i])
+ * of python_code/detectors/VA/va_detector.py:89-97 (== vnet_detector.py:53-59), with
+ * acs_block = python_code/utils/trellis_utils.py:16-30 and in_prob starting at zero (:84).
+ *   cost [B,T,S] contiguous; dec [B, dec_ld>=T]; final_metric [B,S] or NULL.
+ */
+int mvn_acs_sweep_f32(const float *cost, float *dec, int64_t dec_ld, float *final_metric,
+                      int64_t B, int32_t T, int32_t S, mvn_stream_t stream);
+
+/*
+ * VADetector.forward(y,'val'), python_code/detectors/VA/va_detector.py:73-98, given the
+ * state priors of compute_state_priors (:42-50) as a [Bp,S] table (row b uses b % Bp, the
+ * `.repeat` of :64-65): branch costs (y-prior)^2/2 - log(sqrt(2*pi)) (:64-68) are computed in
+ * registers, never written to HBM.   y [B, y_ld>=T].
+ */
+int mvn_va_decode_f32(const float *y, int64_t y_ld, const float *state_priors, int64_t Bp,
+                      float *dec, int64_t dec_ld, float *final_metric, int64_t B, int32_t T,
+                      int32_t S, mvn_stream_t stream);
+
+/*
+ * The ViterbiNet likelihood MLP net(y.reshape(-1,1)),
+ * python_code/detectors/VNET/vnet_detector.py:27-33,49 (== meta_vnet_detector.py:26-32):
+ * Linear(1,100) Sigmoid Linear(100,50) ReLU Linear(50,S).  Weights in torch layout:
+ * W1[100,1] b1[100] W2[50,100] b2[50] W3[S,50] b3[S]; read at call time, never cached.
+ *   y [N] contiguous; logits [N,S].
+ */
+int mvn_vnet_logits_f32(const float *y, const float *W1, const float *b1, const float *W2,
+                        const float *b2, const float *W3, const float *b3, float *logits,
+                        int64_t N, int32_t S, mvn_stream_t stream);
+
+/* Bytes of scratch mvn_vnet_decode_f32 wants to run (B,T,S) in one pass; any size that
+ * holds at least one block (T*S*4 bytes) is accepted and processed in slices. */
+size_t mvn_vnet_workspace_bytes(int64_t B, int32_t T, int32_t S);
+
+/*
+ * VNETDetector.forward(y,'val'), python_code/detectors/VNET/vnet_detector.py:35-61, and
+ * META_VNETDetector.forward(y,'val',var), meta_vnet_detector.py:24-45 (var = the six arrays).
+ *   y [B, y_ld>=T]; dec [B, dec_ld>=T]; logits_out [B,T,S] or NULL; final_metric [B,S] or NULL;
+ *   workspace: device scratch (may be NULL when logits_out is given or the fused S=16 path runs).
+ */
+int mvn_vnet_decode_f32(const float *y, int64_t y_ld, const float *W1, const float *b1,
+                        const float *W2, const float *b2, const float *W3, const float *b3,
+                        float *dec, int64_t dec_ld, float *logits_out, float *final_metric,
+                        void *workspace, size_t workspace_bytes, int64_t B, int32_t T, int32_t S,
+                        mvn_stream_t stream);
+
+/*
+ * calculate_error_rates, python_code/utils/metrics.py:7-17, as integer counters so that
+ * 1/2/4/8-GPU results are identical: counters[0..3] += {bit_errors, bits, frame_errors, frames}
+ * over rows `rows[i]` (int64 device array, or NULL = rows 0..n_rows-1) and the first K columns.
+ * counters: device int64[4], accumulated into (caller zeroes it).
+ */
+int mvn_count_errors(const float *dec, int64_t dec_ld, const float *tx, int64_t tx_ld,
+                     const int64_t *rows, int64_t n_rows, int32_t K, int64_t *counters,
+                     mvn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVN_H_ */

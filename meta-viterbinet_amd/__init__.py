@@ -1,0 +1,18 @@
+"""MI355X-native Viterbi / ViterbiNet detection engine: drop-in 'val' hot path for
+tomerraviv95/meta-viterbinet (C ABI in include/mvn.h, kernels in csrc/mvn_hip.hip)."""
+from . import _lib
+from .channel import BPSKModulator, estimate_channel
+from .detectors import HIDDEN1_SIZE, HIDDEN2_SIZE, META_VNETDetector, VADetector, VNETDetector
+from .harness import (data_indices, detect_by_word, eval_counters, shard_range, sharded_eval,
+                      single_eval_at_point, synthetic_words)
+from .metrics import calculate_error_rates, count_errors, rates_from_counters
+from .trellis import acs_block, acs_sweep, calculate_states, create_transition_table
+
+__all__ = [
+    "VADetector", "VNETDetector", "META_VNETDetector", "HIDDEN1_SIZE", "HIDDEN2_SIZE",
+    "create_transition_table", "acs_block", "acs_sweep", "calculate_states",
+    "calculate_error_rates", "count_errors", "rates_from_counters",
+    "estimate_channel", "BPSKModulator",
+    "shard_range", "data_indices", "synthetic_words", "eval_counters", "single_eval_at_point",
+    "sharded_eval", "detect_by_word",
+]

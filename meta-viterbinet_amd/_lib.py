@@ -1,0 +1,83 @@
+"""ctypes binding of libmvn_hip.so (C ABI: include/mvn.h).
+
+There is deliberately NO CPU fallback: if the HIP library is missing or no gfx950 device is
+usable, every 'val' call raises.  (The CPU oracle under oracle/ is test infrastructure and is
+never imported from here.)
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmvn_hip.so")
+ABI_VERSION = 1
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int32
+
+# name -> (restype, argtypes); mirrors include/mvn.h one to one
+SIGNATURES = {
+    "mvn_version": (ctypes.c_int, []),
+    "mvn_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "mvn_device_info": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                       ctypes.c_char_p, ctypes.c_int]),
+    "mvn_acs_block_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "mvn_acs_sweep_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
+    "mvn_va_decode_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
+    "mvn_vnet_logits_f32": (ctypes.c_int, [_vp] * 8 + [_i64, _i32, _vp]),
+    "mvn_vnet_workspace_bytes": (ctypes.c_size_t, [_i64, _i32, _i32]),
+    "mvn_vnet_decode_f32": (ctypes.c_int, [_vp, _i64] + [_vp] * 6 + [_vp, _i64, _vp, _vp, _vp, ctypes.c_size_t,
+                                                                   _i64, _i32, _i32, _vp]),
+    "mvn_count_errors": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp]),
+}
+
+_lib = None
+
+
+class MvnError(RuntimeError):
+    """A libmvn_hip.so call returned non-zero."""
+
+
+def load():
+    """Load the HIP library; raises (never falls back) if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MvnError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the 'val' path.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if lib.mvn_version() != ABI_VERSION:
+            raise MvnError(f"libmvn_hip.so ABI {lib.mvn_version()} != expected {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().mvn_strerror(rc).decode()
+        if rc in (-1, -3):
+            raise ValueError(f"{what}: {msg}")
+        raise MvnError(f"{what}: {msg} (code {rc})")
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int64 torch tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu_tensor(t, name):
+    if not t.is_cuda:
+        raise MvnError(
+            f"{name} lives on {t.device}: the 'val' hot path only runs on an MI355X (ROCm) device; "
+            "CPU execution is intentionally not provided")

@@ -1,0 +1,60 @@
+"""Host-side channel-tap model needed by the full-CSI VA detector: counterpart of
+python_code/channel/channel_estimation.py:11-49 and python_code/channel/modulator.py:12.
+Tiny float64 NumPy work, evaluated once per forward() on the host exactly like the reference."""
+import os
+
+import numpy as np
+
+COST_LENGTH = 300  # channel_estimation.py:8
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "cost2100_taps.npy")
+COST2100_DIR = None  # optional directory holding combined_h_{i}.mat (the reference's loader layout)
+_cost_cache = {}
+
+
+def _cost2100_table(memory_length: int) -> np.ndarray:
+    key = (COST2100_DIR, memory_length)
+    if key not in _cost_cache:
+        if COST2100_DIR is not None:
+            import scipy.io
+
+            total_h = np.empty([COST_LENGTH, memory_length])
+            for i in range(memory_length):
+                total_h[:, i] = scipy.io.loadmat(os.path.join(COST2100_DIR, f"combined_h_{i}"))[
+                    "h_channel_response_mag"].reshape(-1)
+        else:
+            total_h = np.load(_DATA)  # [300,4] float64 capture of resources/cost2100_channel/h_{0..3}.mat
+            if memory_length != total_h.shape[1]:
+                raise ValueError("cost2100 taps are recorded for memory_length 4 only")
+        _cost_cache[key] = total_h
+    return _cost_cache[key]
+
+
+def estimate_channel(memory_length: int, gamma: float, channel_coefficients: str, noisy_est_var: float = 0,
+                     fading: bool = False, index: int = 0, fading_taps_type: int = 1) -> np.ndarray:
+    """[1,memory_length] float64 taps (channel_estimation.py:11-49)."""
+    if channel_coefficients == "time_decay":
+        h = np.reshape(np.exp(-gamma * np.arange(memory_length)), [1, memory_length])
+    elif channel_coefficients == "cost2100":
+        h = np.reshape(_cost2100_table(memory_length)[index], [1, memory_length]).copy()
+    else:
+        raise ValueError("No such channel_coefficients value!!!")
+    if noisy_est_var > 0:  # global unseeded RNG, as in the reference (:36)
+        h[:, 1:] += np.random.normal(0, noisy_est_var ** 0.5, [1, memory_length - 1])
+    if fading and channel_coefficients == "time_decay":
+        if fading_taps_type == 1:
+            fading_taps = np.array([51, 39, 33, 21])
+            h *= (0.8 + 0.2 * np.cos(2 * np.pi * index / fading_taps)).reshape(1, memory_length)
+        elif fading_taps_type == 2:
+            fading_taps = 5 * np.array([51, 39, 33, 21])
+            fading_taps = np.maximum(fading_taps - 1.5 * index, 10 * np.ones(4)) - 1e-5
+            h *= (0.8 + 0.2 * np.cos(np.pi * index / fading_taps)).reshape(1, memory_length)
+        else:
+            raise ValueError("No such fading tap type!!!")
+    return h
+
+
+class BPSKModulator:
+    @staticmethod
+    def modulate(c: np.ndarray) -> np.ndarray:
+        """0 -> +1, 1 -> -1 (modulator.py:12)"""
+        return 1 - 2 * c

@@ -1,0 +1,566 @@
+// mvn_hip.hip -- gfx950 (MI355X / CDNA4) kernels + C ABI (include/mvn.h) for the
+// Viterbi / ViterbiNet 'val' hot path of tomerraviv95/meta-viterbinet.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC  (see __graft_entry__.build)
+// -ffp-contract=off is part of the arithmetic contract: every reference fp32 op rounds once.
+//
+// Kernels
+//   sweep_kernel<S,MODE>   state-per-lane ACS recurrence (trellis_utils.py:16-30 inside the
+//                          T loop of va_detector.py:89-97); MODE picks the branch-cost source:
+//                          materialised costs, negated logits, or fused VA costs from y.
+//   mlp_kernel<NT3>        ViterbiNet MLP (vnet_detector.py:27-33,49) on f32 MFMA 16x16x4:
+//                          exact k-ordered fmaf chains == torch-CPU sgemm result order.
+//   count_errors_kernel    metrics.py:7-17 as int64 counters.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mvn.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kH1 = 100;  // vnet_detector.py:7
+constexpr int kH2 = 50;   // vnet_detector.py:8
+constexpr int kK2Steps = kH1 / 4;        // 25 MFMA k-steps for layer 2
+constexpr int kK3Steps = (kH2 + 3) / 4;  // 13 MFMA k-steps for layer 3 (k 50,51 zero-padded)
+
+// -------------------------------------------------------------------------------------------
+// Deterministic sigmoid: 1/(1+expf_u10(d)), d = -z.  Same operation sequence as
+// oracle/mvn_oracle.c:mvn_oracle_expf_u10 (SLEEF 1.0-ULP expf as ATen's vectorised sigmoid
+// evaluates it).  v_ldexp_f32 replaces SLEEF's two-step scaling: the two differ only when the
+// result is subnormal, and then 1+e == 1 either way.
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoid_from_neg(float d) {
+    float dc = fminf(fmaxf(d, -128.0f), 128.0f);
+    float t = dc * 1.442695040888963407359924681001892137426645954152985934135449406931f;
+    float qf = __builtin_rintf(t);
+    int q = (int)qf;
+    float s = __builtin_fmaf(qf, -0.693145751953125f, dc);
+    s = __builtin_fmaf(qf, -1.428606765330187045e-06f, s);
+    float u = 0.000198527617612853646278381f;
+    u = __builtin_fmaf(u, s, 0.00139304355252534151077271f);
+    u = __builtin_fmaf(u, s, 0.00833336077630519866943359f);
+    u = __builtin_fmaf(u, s, 0.0416664853692054748535156f);
+    u = __builtin_fmaf(u, s, 0.166666671633720397949219f);
+    u = __builtin_fmaf(u, s, 0.5f);
+    u = 1.0f + __builtin_fmaf(s * s, u, s);
+    float e = ldexpf(u, q);
+    return 1.0f / (1.0f + e);  // IEEE division (hipcc default: correctly rounded)
+}
+
+// va_detector.py:64-68, four separately rounded ops.
+__device__ __forceinline__ float va_cost(float y, float prior) {
+    float d = y - prior;
+    float sq = d * d;
+    float half = sq * 0.5f;
+    return half - 0.91893853320467274178f;
+}
+
+// -------------------------------------------------------------------------------------------
+// Generic sweep: one lane per state (S<=64: 64/S blocks per wave; S=128/256: 2/4 states per
+// lane, one block per wave).  Path metrics live in VGPRs; the predecessor shuffle
+// out[s] = min(a[2s%S], a[(2s+1)%S]) goes through a per-wave LDS row (ds_write_b32 +
+// ds_read_b64); the running argmin is a lexicographic (value,index) xor-butterfly.
+// -------------------------------------------------------------------------------------------
+enum { MODE_COST = 0, MODE_NEGLOGIT = 1, MODE_VA = 2 };
+
+template <int S>
+struct SweepCfg {
+    static constexpr int LPB = S < 64 ? S : 64;  // lanes per block
+    static constexpr int R = S / LPB;            // states per lane
+    static constexpr int G = 64 / LPB;           // blocks per wave
+    static constexpr int TC = S < 8 ? S : 8;     // steps per chunk (decisions stored TC at a time)
+};
+
+constexpr int kSweepWaves = 4;
+
+template <int S, int MODE>
+__global__ __launch_bounds__(64 * kSweepWaves) void sweep_kernel(
+    const float *__restrict__ src, int64_t src_ld, const float *__restrict__ priors, int64_t Bp,
+    float *__restrict__ dec, int64_t dec_ld, float *__restrict__ final_metric, int64_t B, int T) {
+    using C = SweepCfg<S>;
+    constexpr int LPB = C::LPB, R = C::R, G = C::G, TC = C::TC;
+    __shared__ float lds[kSweepWaves][64 * R];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane / LPB;
+    const int sl = lane % LPB;
+    const int64_t b = ((int64_t)blockIdx.x * kSweepWaves + wave) * G + g;
+    const bool active = b < B;
+    const int64_t bc = active ? b : B - 1;
+    float *row = &lds[wave][g * S];
+
+    float m[R], pr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        m[r] = 0.0f;  // va_detector.py:84
+        pr[r] = 0.0f;
+        if (MODE == MODE_VA) pr[r] = priors[(bc % Bp) * S + sl + LPB * r];
+    }
+
+    const float *base = (MODE == MODE_VA) ? src + bc * src_ld : src + bc * (int64_t)T * S;
+    auto load_chunk = [&](int t0, float (&c)[TC][R]) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            int t = t0 + i < T ? t0 + i : T - 1;
+            if (MODE == MODE_VA) {
+                float yv = base[t];
+#pragma unroll
+                for (int r = 0; r < R; ++r) c[i][r] = yv;
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) c[i][r] = base[(int64_t)t * S + sl + LPB * r];
+            }
+        }
+    };
+
+    float cur[TC][R], nxt[TC][R];
+    load_chunk(0, nxt);
+    float mydec = 0.0f;
+    for (int t0 = 0; t0 < T; t0 += TC) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int r = 0; r < R; ++r) cur[i][r] = nxt[i][r];
+        if (t0 + TC < T) load_chunk(t0 + TC, nxt);
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            if (t0 + i < T) {  // wave-uniform
+                // ---- decision: argmin over states, first minimal index (torch.argmin) % 2
+                float bv = m[0];
+                int bi = sl;
+#pragma unroll
+                for (int r = 1; r < R; ++r)
+                    if (m[r] < bv) {
+                        bv = m[r];
+                        bi = sl + LPB * r;
+                    }
+#pragma unroll
+                for (int off = 1; off < LPB; off <<= 1) {
+                    float ov = __shfl_xor(bv, off);
+                    int oi = __shfl_xor(bi, off);
+                    bool take = (ov < bv) || (ov == bv && oi < bi);
+                    bv = take ? ov : bv;
+                    bi = take ? oi : bi;
+                }
+                if (sl == i) mydec = (float)(bi & 1);
+                // ---- ACS stage
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float c = cur[i][r];
+                    if (MODE == MODE_VA) c = va_cost(c, pr[r]);
+                    if (MODE == MODE_NEGLOGIT) c = -c;
+                    row[sl + LPB * r] = m[r] + c;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    int p0 = (2 * (sl + LPB * r)) % S;
+                    float2 v = *reinterpret_cast<const float2 *>(&row[p0]);
+                    m[r] = fminf(v.x, v.y);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        if (active && sl < TC && t0 + sl < T) dec[b * dec_ld + t0 + sl] = mydec;
+    }
+    if (active && final_metric) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) final_metric[b * S + sl + LPB * r] = m[r];
+    }
+}
+
+template <int MODE>
+int launch_sweep(const float *src, int64_t src_ld, const float *priors, int64_t Bp, float *dec,
+                 int64_t dec_ld, float *final_metric, int64_t B, int T, int S, hipStream_t st) {
+    if (B == 0 || T == 0) return MVN_OK;
+#define MVN_SWEEP_CASE(SS)                                                                       \
+    case SS: {                                                                                   \
+        constexpr int per_wg = kSweepWaves * SweepCfg<SS>::G;                                    \
+        int64_t grid = (B + per_wg - 1) / per_wg;                                                \
+        hipLaunchKernelGGL((sweep_kernel<SS, MODE>), dim3((unsigned)grid), dim3(64 * kSweepWaves), \
+                           0, st, src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T);     \
+        break;                                                                                   \
+    }
+    switch (S) {
+        MVN_SWEEP_CASE(2)
+        MVN_SWEEP_CASE(4)
+        MVN_SWEEP_CASE(8)
+        MVN_SWEEP_CASE(16)
+        MVN_SWEEP_CASE(32)
+        MVN_SWEEP_CASE(64)
+        MVN_SWEEP_CASE(128)
+        MVN_SWEEP_CASE(256)
+        default:
+            return MVN_E_STATES;
+    }
+#undef MVN_SWEEP_CASE
+    return (int)hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------
+// ViterbiNet MLP on f32 MFMA (v_mfma_f32_16x16x4_f32: D[16x16] += A[16x4] B[4x16], exact
+// k-ordered fmaf chain).  One wave owns a tile of 16 symbols:
+//   layer 1+sigmoid : lane (j=l&15, q=l>>4) evaluates hidden-1 units k = 4i+q, i<25, for its
+//                     symbol j straight into the B-operand layout (B[k=q][col=j]);
+//   layer 2         : A = W2 rows (hidden-2 units, 50 padded to 64 = 4 row tiles), 100 VGPRs of
+//                     weights held for the kernel's lifetime; 100 MFMAs per symbol tile;
+//   bias + ReLU     : in the D layout (row = 4q+r);
+//   (q,r) transpose : v_permlane32_swap + v_permlane16_swap turn D rows into the next
+//                     B operand in natural k order (torch's accumulation order);
+//   layer 3         : A = W3 rows (states, ceil(S/16) tiles) read from LDS; 13 MFMAs per tile.
+// -------------------------------------------------------------------------------------------
+constexpr int kMlpWaves = 4;
+
+template <int NT3>
+__global__ __launch_bounds__(64 * kMlpWaves, 2) void mlp_kernel(
+    const float *__restrict__ y, int64_t y_ld, int T, int64_t N, const float *__restrict__ W1,
+    const float *__restrict__ b1, const float *__restrict__ W2, const float *__restrict__ b2,
+    const float *__restrict__ W3, const float *__restrict__ b3, float *__restrict__ out, int S) {
+    __shared__ float ldsA3[NT3 * kK3Steps * 64];
+    __shared__ float ldsB3[NT3 * 16];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 15;
+    const int q = lane >> 4;
+
+    // stage W3 in A-operand order: element (j3,i3,lane) = W3[16*j3 + (lane&15)][4*i3 + (lane>>4)]
+    for (int e = threadIdx.x; e < NT3 * kK3Steps * 64; e += blockDim.x) {
+        int l = e & 63, i3 = (e >> 6) % kK3Steps, j3 = (e >> 6) / kK3Steps;
+        int st = 16 * j3 + (l & 15), k = 4 * i3 + (l >> 4);
+        ldsA3[e] = (st < S && k < kH2) ? W3[st * kH2 + k] : 0.0f;
+    }
+    for (int e = threadIdx.x; e < NT3 * 16; e += blockDim.x) ldsB3[e] = e < S ? b3[e] : 0.0f;
+
+    float nw1[kK2Steps], nb1[kK2Steps], a2[4][kK2Steps], b2v[4][4];
+#pragma unroll
+    for (int i = 0; i < kK2Steps; ++i) {
+        nw1[i] = -W1[4 * i + q];
+        nb1[i] = -b1[4 * i + q];
+    }
+#pragma unroll
+    for (int tau = 0; tau < 4; ++tau) {
+        int unit = 16 * tau + j;
+#pragma unroll
+        for (int i = 0; i < kK2Steps; ++i) a2[tau][i] = unit < kH2 ? W2[unit * kH1 + 4 * i + q] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int u = 16 * tau + 4 * q + r;
+            b2v[tau][r] = u < kH2 ? b2[u] : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    const int64_t ntiles = (N + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * kMlpWaves + wave; tile < ntiles;
+         tile += (int64_t)gridDim.x * kMlpWaves) {
+        const int64_t n = tile * 16 + j;
+        const int64_t nc = n < N ? n : N - 1;
+        const float yj = y[(nc / T) * y_ld + (nc % T)];
+
+        f32x4 acc[4];
+#pragma unroll
+        for (int tau = 0; tau < 4; ++tau) acc[tau] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < kK2Steps; ++i) {
+            // -(fma(y,w1,b1)) == fma(y,-w1,-b1): the argument of exp in torch's sigmoid
+            float h = sigmoid_from_neg(__builtin_fmaf(yj, nw1[i], nb1[i]));
+#pragma unroll
+            for (int tau = 0; tau < 4; ++tau)
+                acc[tau] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[tau][i], h, acc[tau], 0, 0, 0);
+        }
+
+        // bias + ReLU in D layout, then (q,r) transpose into B-operand order: bop[4*tau+r'] at
+        // lane (j,q) = h2[unit 16*tau + 4*r' + q][symbol j]
+        float bop[16];
+#pragma unroll
+        for (int tau = 0; tau < 4; ++tau) {
+            unsigned u[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float z = acc[tau][r] + b2v[tau][r];
+                u[r] = __float_as_uint(z > 0.0f ? z : 0.0f);
+            }
+            u32x2 p;
+            p = __builtin_amdgcn_permlane32_swap(u[0], u[2], false, false);
+            u[0] = p[0];
+            u[2] = p[1];
+            p = __builtin_amdgcn_permlane32_swap(u[1], u[3], false, false);
+            u[1] = p[0];
+            u[3] = p[1];
+            p = __builtin_amdgcn_permlane16_swap(u[0], u[1], false, false);
+            u[0] = p[0];
+            u[1] = p[1];
+            p = __builtin_amdgcn_permlane16_swap(u[2], u[3], false, false);
+            u[2] = p[0];
+            u[3] = p[1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bop[4 * tau + r] = __uint_as_float(u[r]);
+        }
+
+        auto out_tile = [&](int j3) {
+            f32x4 acc3 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i3 = 0; i3 < kK3Steps; ++i3)
+                acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(ldsA3[(j3 * kK3Steps + i3) * 64 + lane], bop[i3],
+                                                            acc3, 0, 0, 0);
+            const int st0 = 16 * j3 + 4 * q;
+            if (n < N) {
+                float *o = out + n * S + st0;
+                if (st0 + 3 < S) {
+                    float4 v;
+                    v.x = acc3[0] + ldsB3[st0 + 0];
+                    v.y = acc3[1] + ldsB3[st0 + 1];
+                    v.z = acc3[2] + ldsB3[st0 + 2];
+                    v.w = acc3[3] + ldsB3[st0 + 3];
+                    *reinterpret_cast<float4 *>(o) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (st0 + r < S) o[r] = acc3[r] + ldsB3[st0 + r];
+                }
+            }
+        };
+        if constexpr (NT3 <= 2) {
+#pragma unroll
+            for (int j3 = 0; j3 < NT3; ++j3) out_tile(j3);
+        } else {
+#pragma unroll 1
+            for (int j3 = 0; j3 < NT3; ++j3) out_tile(j3);
+        }
+    }
+}
+
+int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, const float *b1,
+               const float *W2, const float *b2, const float *W3, const float *b3, float *out, int S,
+               hipStream_t st) {
+    if (N == 0) return MVN_OK;
+    const int64_t ntiles = (N + 15) / 16;
+    int64_t want = (ntiles + kMlpWaves - 1) / kMlpWaves;
+    const int64_t cap = 256 * 2 * 4;  // 2 workgroups per CU resident, a few rounds of slack
+    unsigned grid = (unsigned)(want < cap ? want : cap);
+    const int nt3 = (S + 15) / 16;
+#define MVN_MLP_CASE(NT)                                                                          \
+    case NT:                                                                                      \
+        hipLaunchKernelGGL((mlp_kernel<NT>), dim3(grid), dim3(64 * kMlpWaves), 0, st, y, y_ld, T, N, \
+                           W1, b1, W2, b2, W3, b3, out, S);                                       \
+        break;
+    switch (nt3) {
+        MVN_MLP_CASE(1)
+        MVN_MLP_CASE(2)
+        MVN_MLP_CASE(4)
+        MVN_MLP_CASE(8)
+        MVN_MLP_CASE(16)
+        default:
+            return MVN_E_STATES;
+    }
+#undef MVN_MLP_CASE
+    return (int)hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------
+// metrics.py:7-17 as integer counters.  One wave per row, block-level reduction, one atomic
+// per workgroup per counter.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void count_errors_kernel(const float *__restrict__ dec, int64_t dec_ld,
+                                                           const float *__restrict__ tx, int64_t tx_ld,
+                                                           const int64_t *__restrict__ rows, int64_t n_rows,
+                                                           int K, unsigned long long *counters) {
+    __shared__ unsigned long long s_be, s_fe;
+    if (threadIdx.x == 0) {
+        s_be = 0;
+        s_fe = 0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    unsigned long long be = 0, fe = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n_rows; i += (int64_t)gridDim.x * 4) {
+        const int64_t r = rows ? rows[i] : i;
+        int e = 0;
+        for (int k = lane; k < K; k += 64)
+            e += ((long long)dec[r * dec_ld + k] != (long long)tx[r * tx_ld + k]) ? 1 : 0;  // .long() then eq
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
+        be += (unsigned long long)e;
+        fe += e ? 1ull : 0ull;
+    }
+    if (lane == 0) {
+        atomicAdd(&s_be, be);
+        atomicAdd(&s_fe, fe);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_be) atomicAdd(&counters[0], s_be);
+        if (s_fe) atomicAdd(&counters[2], s_fe);
+        if (blockIdx.x == 0) {
+            atomicAdd(&counters[1], (unsigned long long)n_rows * (unsigned long long)K);
+            atomicAdd(&counters[3], (unsigned long long)n_rows);
+        }
+    }
+}
+
+// trellis_utils.py:16-30, one stage, one thread per (block,state).
+__global__ __launch_bounds__(256) void acs_block_kernel(const float *__restrict__ in_prob,
+                                                        const float *__restrict__ llrs, float *__restrict__ out,
+                                                        long long *__restrict__ argmin_j, int64_t B, int S) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * S) return;
+    const int64_t b = e / S;
+    const int s = (int)(e % S);
+    const int p0 = (2 * s) % S, p1 = (2 * s + 1) % S;
+    const float v0 = in_prob[b * S + p0] + llrs[b * S + p0];
+    const float v1 = in_prob[b * S + p1] + llrs[b * S + p1];
+    const bool second = v1 < v0;  // first minimal index wins
+    out[e] = second ? v1 : v0;
+    if (argmin_j) argmin_j[e] = second ? 1 : 0;
+}
+
+bool valid_states(int S) { return S >= 2 && S <= 256 && (S & (S - 1)) == 0; }
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int mvn_version(void) { return MVN_ABI_VERSION; }
+
+const char *mvn_strerror(int code) {
+    switch (code) {
+        case MVN_OK: return "ok";
+        case MVN_E_DIMS: return "mvn: bad dimensions (negative size or T larger than a row stride)";
+        case MVN_E_STATES: return "mvn: n_states must be a power of two in [2,256]";
+        case MVN_E_PRIORS: return "mvn: state-prior table rows must be >=1 and divide the batch";
+        case MVN_E_NULL: return "mvn: required pointer is NULL";
+        case MVN_E_WORKSPACE: return "mvn: workspace smaller than one block of logits";
+        case MVN_E_DEVICE: return "mvn: current HIP device is not gfx950";
+        default: break;
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "mvn: unknown error";
+}
+
+int mvn_device_info(int *n_cu, int *lds_bytes_per_cu, char *arch_name, int arch_name_len) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) return (int)e;
+    if (n_cu) *n_cu = p.multiProcessorCount;
+    if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)p.maxSharedMemoryPerMultiProcessor;
+    if (arch_name && arch_name_len > 0) {
+        int i = 0;
+        for (; i < arch_name_len - 1 && p.gcnArchName[i]; ++i) arch_name[i] = p.gcnArchName[i];
+        arch_name[i] = 0;
+    }
+    const char *a = p.gcnArchName;
+    return (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? MVN_OK
+                                                                                                  : MVN_E_DEVICE;
+}
+
+int mvn_acs_block_f32(const float *in_prob, const float *llrs, float *out, int64_t *argmin_j, int64_t B,
+                      int32_t S, mvn_stream_t stream) {
+    if (B < 0) return MVN_E_DIMS;
+    if (!valid_states(S)) return MVN_E_STATES;
+    if (B == 0) return MVN_OK;
+    if (!in_prob || !llrs || !out) return MVN_E_NULL;
+    const int64_t n = B * S;
+    hipLaunchKernelGGL(acs_block_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       in_prob, llrs, out, (long long *)argmin_j, B, S);
+    return (int)hipGetLastError();
+}
+
+int mvn_acs_sweep_f32(const float *cost, float *dec, int64_t dec_ld, float *final_metric, int64_t B,
+                      int32_t T, int32_t S, mvn_stream_t stream) {
+    if (B < 0 || T < 0 || dec_ld < T) return MVN_E_DIMS;
+    if (!valid_states(S)) return MVN_E_STATES;
+    if (B == 0 || T == 0) return MVN_OK;
+    if (!cost || !dec) return MVN_E_NULL;
+    return launch_sweep<MODE_COST>(cost, 0, nullptr, 1, dec, dec_ld, final_metric, B, T, S,
+                                   (hipStream_t)stream);
+}
+
+int mvn_va_decode_f32(const float *y, int64_t y_ld, const float *state_priors, int64_t Bp, float *dec,
+                      int64_t dec_ld, float *final_metric, int64_t B, int32_t T, int32_t S,
+                      mvn_stream_t stream) {
+    if (B < 0 || T < 0 || dec_ld < T || y_ld < T) return MVN_E_DIMS;
+    if (!valid_states(S)) return MVN_E_STATES;
+    if (Bp < 1 || (B % Bp) != 0) return MVN_E_PRIORS;
+    if (B == 0 || T == 0) return MVN_OK;
+    if (!y || !state_priors || !dec) return MVN_E_NULL;
+    return launch_sweep<MODE_VA>(y, y_ld, state_priors, Bp, dec, dec_ld, final_metric, B, T, S,
+                                 (hipStream_t)stream);
+}
+
+int mvn_vnet_logits_f32(const float *y, const float *W1, const float *b1, const float *W2, const float *b2,
+                        const float *W3, const float *b3, float *logits, int64_t N, int32_t S,
+                        mvn_stream_t stream) {
+    if (N < 0) return MVN_E_DIMS;
+    if (!valid_states(S)) return MVN_E_STATES;
+    if (N == 0) return MVN_OK;
+    if (!y || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !logits) return MVN_E_NULL;
+    const int T = N < (int64_t)1 << 30 ? (int)N : 1 << 30;
+    return launch_mlp(y, T, T, N, W1, b1, W2, b2, W3, b3, logits, S, (hipStream_t)stream);
+}
+
+size_t mvn_vnet_workspace_bytes(int64_t B, int32_t T, int32_t S) {
+    if (B <= 0 || T <= 0 || S <= 0) return 0;
+    return (size_t)B * (size_t)T * (size_t)S * sizeof(float);
+}
+
+int mvn_vnet_decode_f32(const float *y, int64_t y_ld, const float *W1, const float *b1, const float *W2,
+                        const float *b2, const float *W3, const float *b3, float *dec, int64_t dec_ld,
+                        float *logits_out, float *final_metric, void *workspace, size_t workspace_bytes,
+                        int64_t B, int32_t T, int32_t S, mvn_stream_t stream) {
+    if (B < 0 || T < 0 || dec_ld < T || y_ld < T) return MVN_E_DIMS;
+    if (!valid_states(S)) return MVN_E_STATES;
+    if (B == 0 || T == 0) return MVN_OK;
+    if (!y || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !dec) return MVN_E_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t per_block = (size_t)T * (size_t)S * sizeof(float);
+    int64_t slice = B;
+    float *buf = logits_out;
+    if (!buf) {
+        if (!workspace) return MVN_E_NULL;
+        slice = (int64_t)(workspace_bytes / per_block);
+        if (slice < 1) return MVN_E_WORKSPACE;
+        if (slice > B) slice = B;
+        buf = (float *)workspace;
+    }
+    for (int64_t b0 = 0; b0 < B; b0 += slice) {
+        const int64_t nb = (B - b0 < slice) ? B - b0 : slice;
+        float *lg = logits_out ? logits_out + (size_t)b0 * T * S : buf;
+        int rc = launch_mlp(y + b0 * y_ld, y_ld, T, nb * T, W1, b1, W2, b2, W3, b3, lg, S, st);
+        if (rc) return rc;
+        rc = launch_sweep<MODE_NEGLOGIT>(lg, 0, nullptr, 1, dec + b0 * dec_ld, dec_ld,
+                                         final_metric ? final_metric + b0 * S : nullptr, nb, T, S, st);
+        if (rc) return rc;
+    }
+    return MVN_OK;
+}
+
+int mvn_count_errors(const float *dec, int64_t dec_ld, const float *tx, int64_t tx_ld, const int64_t *rows,
+                     int64_t n_rows, int32_t K, int64_t *counters, mvn_stream_t stream) {
+    if (n_rows < 0 || K < 0 || dec_ld < K || tx_ld < K) return MVN_E_DIMS;
+    if (!counters) return MVN_E_NULL;
+    if (n_rows == 0 || K == 0) return MVN_OK;
+    if (!dec || !tx) return MVN_E_NULL;
+    int64_t want = (n_rows + 3) / 4;
+    unsigned grid = (unsigned)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(count_errors_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dec, dec_ld, tx,
+                       tx_ld, rows, n_rows, K, (unsigned long long *)counters);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

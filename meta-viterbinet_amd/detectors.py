@@ -1,0 +1,198 @@
+"""Drop-in detectors: same constructors, forward() signatures, parameter names and exceptions as
+python_code/detectors/{VA/va_detector.py, VNET/vnet_detector.py, META_VNET/meta_vnet_detector.py};
+phase 'val' runs on the MI355X through libmvn_hip.so, phase 'train' is plain torch (autograd)."""
+import math
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import functional as F
+
+from . import _lib
+from .channel import BPSKModulator, estimate_channel
+from .trellis import create_transition_table
+
+HIDDEN1_SIZE = 100  # vnet_detector.py:7
+HIDDEN2_SIZE = 50  # vnet_detector.py:8
+_WORKSPACE_CAP = 2 << 30  # bytes of logits scratch per call on the non-fused path
+
+
+def _default_device():
+    return torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+def _as_f32(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t.contiguous()
+
+
+def _check_T(T: int, y: torch.Tensor):
+    if T > y.shape[1]:  # the reference indexes priors[:, i] for i < transmission_length (Q5)
+        raise IndexError(f"index {y.shape[1]} is out of bounds for dimension 1 with size {y.shape[1]}")
+
+
+class VADetector(nn.Module):
+    """Classic full-CSI Viterbi detector (va_detector.py:13-100)."""
+
+    def __init__(self, n_states: int, memory_length: int, transmission_length: int, val_words: int,
+                 channel_type: str, noisy_est_var: float, fading: bool, fading_taps_type: int,
+                 channel_coefficients):
+        super().__init__()
+        self.memory_length = memory_length
+        self.transmission_length = transmission_length
+        self.val_words = val_words
+        self.n_states = n_states
+        self.channel_type = channel_type
+        self.noisy_est_var = noisy_est_var
+        self.fading = fading
+        self.fading_taps_type = fading_taps_type
+        self.channel_coefficients = channel_coefficients  # dict {'train':..., 'val':...} (trainer.py:195)
+        self.transition_table_array = create_transition_table(n_states)
+        self.transition_table = torch.Tensor(self.transition_table_array).to(_default_device())
+
+    def _estimate_all(self, gamma: float, phase: str) -> np.ndarray:
+        """[val_words, L] float64 taps, one estimate_channel call per word (va_detector.py:54-58)."""
+        return np.concatenate(
+            [estimate_channel(self.memory_length, gamma, noisy_est_var=self.noisy_est_var, fading=self.fading,
+                              index=index, fading_taps_type=self.fading_taps_type,
+                              channel_coefficients=self.channel_coefficients[phase])
+             for index in range(self.val_words)], axis=0)
+
+    def compute_state_priors(self, h: np.ndarray) -> torch.Tensor:
+        """Noise-free channel output per state, [n_states, W] fp32 (va_detector.py:42-50)."""
+        all_states_decimal = np.arange(self.n_states).astype(np.uint8).reshape(-1, 1)
+        all_states_binary = np.unpackbits(all_states_decimal, axis=1).astype(int)
+        if self.channel_type == "ISI_AWGN":
+            all_states_symbols = BPSKModulator.modulate(all_states_binary[:, -self.memory_length:])
+        else:
+            raise Exception("No such channel defined!!!")
+        state_priors = np.dot(all_states_symbols, h.T)
+        return torch.Tensor(state_priors).to(_default_device())
+
+    def compute_likelihood_priors(self, y: torch.Tensor, snr: float, gamma: float, phase: str, count: int = None):
+        """Materialised branch costs [B,T,S] (va_detector.py:52-71).  forward() does NOT use this (the
+        kernel computes the same four fp32 ops in registers); kept for API parity / inspection."""
+        pri = self._priors_table(y, gamma, phase, count)  # [W,S]
+        priors = y.unsqueeze(dim=2) - pri.repeat(repeats=[y.shape[0] // pri.shape[0], 1]).unsqueeze(dim=1)
+        return priors ** 2 / 2 - math.log(math.sqrt(2 * math.pi))
+
+    def _priors_table(self, y, gamma, phase, count):
+        h = self._estimate_all(gamma, phase)
+        if count is not None:
+            h = h[count].reshape(1, -1)
+        if self.channel_type != "ISI_AWGN":
+            raise Exception("No such channel defined!!!")
+        return self.compute_state_priors(h).to(y.device).T.contiguous()  # [W,S]
+
+    def forward(self, y: torch.Tensor, phase: str, snr: float = None, gamma: float = None,
+                count: int = None) -> torch.Tensor:
+        """Detected words, same shape as y, fp32 {0.,1.} (va_detector.py:73-100)."""
+        if phase != "val":
+            raise NotImplementedError("No implemented training for this decoder!!!")
+        _lib.require_gpu_tensor(y, "y")
+        yc = _as_f32(y)
+        B, Ty = yc.shape
+        T = self.transmission_length
+        pri = self._priors_table(yc, gamma, phase, count)
+        W = pri.shape[0]
+        if B % W != 0:
+            raise RuntimeError(f"The size of tensor a ({B}) must match the size of tensor b ({W * (B // W)}) "
+                               "at non-singleton dimension 0")
+        _check_T(T, yc)
+        decoded_word = torch.zeros(yc.shape, dtype=torch.float32, device=yc.device)
+        with torch.cuda.device(yc.device):
+            rc = _lib.load().mvn_va_decode_f32(_lib.ptr(yc), Ty, _lib.ptr(pri), W, _lib.ptr(decoded_word), Ty,
+                                               None, B, T, self.n_states, _lib.current_stream(yc.device))
+        _lib.check(rc, "mvn_va_decode_f32")
+        return decoded_word
+
+
+def _vnet_val(y: torch.Tensor, params, n_states: int, T: int, return_logits: bool = False):
+    """Shared 'val' path of VNETDetector / META_VNETDetector -> mvn_vnet_decode_f32."""
+    _lib.require_gpu_tensor(y, "y")
+    yc = _as_f32(y)
+    B, Ty = yc.shape
+    _check_T(T, yc)
+    w = [_as_f32(p).to(yc.device) for p in params]  # read at call time, never cached (python_utils.py:17-27)
+    shapes = [(HIDDEN1_SIZE, 1), (HIDDEN1_SIZE,), (HIDDEN2_SIZE, HIDDEN1_SIZE), (HIDDEN2_SIZE,),
+              (n_states, HIDDEN2_SIZE), (n_states,)]
+    if [tuple(t.shape) for t in w] != shapes:
+        raise ValueError(f"ViterbiNet parameter shapes {[tuple(t.shape) for t in w]} != {shapes}")
+    lib = _lib.load()
+    decoded_word = torch.zeros(yc.shape, dtype=torch.float32, device=yc.device)
+    logits = torch.empty((B, T, n_states), dtype=torch.float32, device=yc.device) if return_logits else None
+    ws, ws_bytes = None, 0
+    if logits is None:
+        ws_bytes = min(int(lib.mvn_vnet_workspace_bytes(B, T, n_states)), _WORKSPACE_CAP)
+        ws_bytes = max(ws_bytes, T * n_states * 4)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=yc.device)
+    with torch.cuda.device(yc.device):
+        rc = lib.mvn_vnet_decode_f32(_lib.ptr(yc), Ty, *[_lib.ptr(t) for t in w], _lib.ptr(decoded_word), Ty,
+                                     _lib.ptr(logits), None, _lib.ptr(ws), ws_bytes, B, T, n_states,
+                                     _lib.current_stream(yc.device))
+    _lib.check(rc, "mvn_vnet_decode_f32")
+    return (decoded_word, logits) if return_logits else decoded_word
+
+
+class VNETDetector(nn.Module):
+    """ViterbiNet: the VA sweep with branch metrics from a per-symbol MLP (vnet_detector.py:11-63).
+    Parameter names net.{0,2,4}.{weight,bias} match the reference so checkpoints interchange."""
+
+    def __init__(self, n_states: int, transmission_lengths: Dict[str, int]):
+        super().__init__()
+        self.transmission_lengths = transmission_lengths
+        self.n_states = n_states
+        self.transition_table_array = create_transition_table(n_states)
+        self.transition_table = torch.Tensor(self.transition_table_array).to(_default_device())
+        self.initialize_dnn()
+
+    def initialize_dnn(self):
+        layers = [nn.Linear(1, HIDDEN1_SIZE), nn.Sigmoid(), nn.Linear(HIDDEN1_SIZE, HIDDEN2_SIZE), nn.ReLU(),
+                  nn.Linear(HIDDEN2_SIZE, self.n_states)]
+        self.net = nn.Sequential(*layers).to(_default_device())
+
+    def forward(self, y: torch.Tensor, phase: str, snr: float = None, gamma: float = None,
+                count: int = None) -> torch.Tensor:
+        """'val' -> detected words [B,T]; otherwise the logits [B,T,S] with autograd (vnet_detector.py:35-63)."""
+        if phase == "val":
+            return _vnet_val(y, list(self.net.parameters()), self.n_states, self.transmission_lengths["val"])
+        return self.net(y.reshape(-1, 1)).reshape(y.shape[0], y.shape[1], self.n_states)
+
+    @torch.no_grad()
+    def logits(self, y: torch.Tensor) -> torch.Tensor:
+        """Inference-only logits [*, S] from the HIP MLP kernel (bit-identical to the 'val' path's)."""
+        _lib.require_gpu_tensor(y, "y")
+        yc = _as_f32(y).reshape(-1)
+        w = [_as_f32(p).to(yc.device) for p in self.net.parameters()]
+        out = torch.empty((yc.numel(), self.n_states), dtype=torch.float32, device=yc.device)
+        with torch.cuda.device(yc.device):
+            rc = _lib.load().mvn_vnet_logits_f32(_lib.ptr(yc), *[_lib.ptr(t) for t in w], _lib.ptr(out),
+                                                 yc.numel(), self.n_states, _lib.current_stream(yc.device))
+        _lib.check(rc, "mvn_vnet_logits_f32")
+        return out.reshape(tuple(y.shape) + (self.n_states,))
+
+
+class META_VNETDetector(nn.Module):
+    """Functional ViterbiNet: weights arrive as var=[W1,b1,W2,b2,W3,b3] so MAML can differentiate
+    through an inner step (meta_vnet_detector.py:11-47).  Owns no parameters."""
+
+    def __init__(self, n_states: int, transmission_lengths: Dict[str, int]):
+        super().__init__()
+        self.transmission_lengths = transmission_lengths
+        self.n_states = n_states
+        self.transition_table_array = create_transition_table(n_states)
+        self.transition_table = torch.Tensor(self.transition_table_array).to(_default_device())
+
+    def forward(self, y: torch.Tensor, phase: str, var: list) -> torch.Tensor:
+        if phase == "val":
+            return _vnet_val(y, list(var), self.n_states, self.transmission_lengths["val"])
+        x = y.reshape(-1, 1)
+        x = F.linear(x, var[0], var[1])
+        x = torch.sigmoid(x)
+        x = F.linear(x, var[2], var[3])
+        x = F.relu(x)
+        x = F.linear(x, var[4], var[5])
+        return x.reshape(y.shape[0], y.shape[1], self.n_states)

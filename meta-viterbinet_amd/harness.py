@@ -1,0 +1,114 @@
+"""Evaluation harness for the detection hot path: counterpart of Trainer.single_eval_at_point /
+gamma_eval / eval_by_word's detector calls (python_code/trainers/trainer.py:222-265, 292-295), plus the
+block-parallel multi-GPU Monte-Carlo loop the reference does not have.
+
+Blocks (words) are independent, so the batch axis is split contiguously across ranks; every rank
+decodes its rows, counts errors on the device as integers, and ONE all_reduce(SUM) of an int64[4]
+tensor {bit_errors, bits, frame_errors, frames} (RCCL over xGMI when backend='nccl') ends the run.
+Decisions are never gathered.  Integer counters make 1/2/4/8-GPU results identical."""
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import metrics as _metrics
+from .channel import estimate_channel
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous split of n rows: rank r owns [lo, hi); sizes differ by at most one."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def data_indices(val_frames: int, subframes_in_frame: int) -> torch.Tensor:
+    """Non-pilot rows: every row whose index is not a multiple of subframes_in_frame (trainer.py:100-102)."""
+    idx = [i for i in range(val_frames * subframes_in_frame) if i % subframes_in_frame != 0]
+    return torch.tensor(idx, dtype=torch.int64)
+
+
+def synthetic_words(n_words: int, block_length: int, memory_length: int, snr: float, gamma: float,
+                    device, seed: int, channel_coefficients: str = "time_decay"):
+    """At-scale synthetic inputs generated on `device`: bits ~ Bernoulli(1/2), zero-padded by
+    L, BPSK 1-2c, anti-causal ISI y[t] = sum_k h[L-1-k] s[t+k] + w[t] (channel.py:25-27), w ~ N(0, 10^(-snr/10)).
+    Same distribution as ChannelModelDataset (channel_dataset.py:55-95), different RNG stream.
+    Returns (tx [n,block_length] fp32 {0,1}, y [n,block_length] fp32)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    L = memory_length
+    tx = torch.randint(0, 2, (n_words, block_length), generator=g, device=device, dtype=torch.int8).to(torch.float32)
+    s = 1.0 - 2.0 * torch.cat([tx, torch.zeros(n_words, L, device=device)], dim=1)
+    h = torch.tensor(estimate_channel(L, gamma, channel_coefficients)[0], dtype=torch.float32, device=device)
+    y = torch.zeros(n_words, block_length, device=device)
+    for k in range(L):
+        y += h[L - 1 - k] * s[:, k:k + block_length]
+    y += (10.0 ** (-snr / 20.0)) * torch.randn(n_words, block_length, generator=g, device=device)
+    return tx, y
+
+
+def _gpu_counter(detected: torch.Tensor, tx: torch.Tensor, rows: Optional[torch.Tensor]) -> torch.Tensor:
+    return _metrics.count_errors(detected, tx, rows)
+
+
+def eval_counters(detector: Callable, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma: float,
+                  rows: Optional[torch.Tensor] = None, counter: Callable = _gpu_counter,
+                  group=None, reduce: bool = True) -> torch.Tensor:
+    """One Monte-Carlo point on THIS rank's rows: detect -> count -> (optionally) all-reduce.
+    `tx`/`rx` are the rank-local shards; `rows` are local row indices counted (None = all).
+    Returns int64[4] counters (global sums when reduce=True and a process group is up)."""
+    detected = detector(rx, "val", snr, gamma)
+    counters = counter(detected[:, : tx.shape[1]], tx, rows)
+    if reduce and dist.is_available() and dist.is_initialized():
+        dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=group)
+    return counters
+
+
+def single_eval_at_point(detector: Callable, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma: float,
+                         rows: Optional[torch.Tensor] = None, counter: Callable = _gpu_counter,
+                         group=None) -> Tuple[float, float, torch.Tensor]:
+    """trainer.py:222-241 without the data draw and the optional RS stage: returns (ser, fer, counters);
+    the reference returns ser only and drops fer (:238-241)."""
+    counters = eval_counters(detector, tx, rx, snr, gamma, rows, counter, group)
+    ser, fer = _metrics.rates_from_counters(counters)
+    return ser, fer, counters
+
+
+def sharded_eval(detector: Callable, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma: float,
+                 rows: Optional[torch.Tensor] = None, counter: Callable = _gpu_counter, group=None,
+                 rank: Optional[int] = None, world: Optional[int] = None) -> Tuple[float, float, torch.Tensor]:
+    """Same point, but given the FULL (tx, rx) on every rank: each rank takes its contiguous row shard
+    (shard_range), maps the global `rows` filter into it, and the counters are all-reduced."""
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    lo, hi = shard_range(tx.shape[0], rank, world)
+    local_rows = None
+    if rows is not None:
+        r = rows.to("cpu")
+        r = r[(r >= lo) & (r < hi)] - lo
+        local_rows = r.to(tx.device)
+    if hi > lo:
+        counters = eval_counters(detector, tx[lo:hi], rx[lo:hi], snr, gamma, local_rows, counter, group, reduce=False)
+    else:
+        counters = torch.zeros(4, dtype=torch.int64, device=tx.device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=group)
+    ser, fer = _metrics.rates_from_counters(counters)
+    return ser, fer, counters
+
+
+def detect_by_word(detector: Callable, rx: torch.Tensor, snr: float, gamma: float, batched: bool = True,
+                   pass_count: bool = False) -> torch.Tensor:
+    """The detector calls of eval_by_word (trainer.py:292-295) when no online update runs between blocks
+    ("joint" variant): block k's decision does not depend on blocks < k, so the 300 B=1 calls collapse
+    into one batched call (batched=True) -- or are issued one by one exactly like the reference."""
+    if batched and not pass_count:
+        return detector(rx, "val", snr, gamma)
+    outs = []
+    for count in range(rx.shape[0]):
+        word = rx[count].reshape(1, -1)
+        outs.append(detector(word, "val", snr, gamma, count) if pass_count else detector(word, "val", snr, gamma))
+    return torch.cat(outs, dim=0)

@@ -1,0 +1,12 @@
+"""Import alias: the package directory is named `meta-viterbinet_amd` (not a Python identifier);
+`import meta_viterbinet_amd as mvn` loads it under this importable name."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "meta-viterbinet_amd")
+_spec = importlib.util.spec_from_file_location(__name__, os.path.join(_dir, "__init__.py"),
+                                               submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)

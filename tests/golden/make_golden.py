@@ -282,6 +282,10 @@ def g6_channels():
         out[f"time_decay_L{L}"] = chest.estimate_channel(L, 0.2, "time_decay")
     out["time_decay_gamma05"] = chest.estimate_channel(4, 0.5, "time_decay")
     save("g6_channels", **out)
+    # the same [300,4] float64 COST2100 tap table, as the data file the package's channel.py reads
+    data_dir = os.path.join(os.path.dirname(os.path.dirname(HERE)), "meta-viterbinet_amd", "data")
+    os.makedirs(data_dir, exist_ok=True)
+    np.save(os.path.join(data_dir, "cost2100_taps.npy"), out["cost2100"])
 
 
 # ----------------------------------------------------------------------------- G7

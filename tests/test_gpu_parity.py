@@ -1,0 +1,299 @@
+"""GPU parity tests (pytest -m gpu, on the MI355X box).  Everything goes through the C ABI of
+libmvn_hip.so (via the ctypes binding) and is compared BIT-EXACTLY with (i) the golden vectors captured
+from the reference and (ii) the CPU oracle on seeded inputs.  The only tolerance anywhere is written in
+test_vnet_scalar_tail_tolerance (a property of torch-CPU, not of the kernels)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import meta_viterbinet_amd as mvn
+
+pytestmark = pytest.mark.gpu
+
+CC = {"train": "time_decay", "val": "time_decay"}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    lib = mvn._lib.load()
+    n_cu = ctypes.c_int()
+    name = ctypes.create_string_buffer(64)
+    rc = lib.mvn_device_info(ctypes.byref(n_cu), None, name, 64)
+    assert rc == 0, f"not a gfx950 device: {name.value!r}"
+    return torch.device("cuda:0")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _weights_t(w, dev):
+    return [torch.tensor(a, device=dev) for a in w]
+
+
+def _vnet_with(w, S, T, dev):
+    det = mvn.VNETDetector(S, {"train": T, "val": T}).to(dev)
+    with torch.no_grad():
+        for p, a in zip(det.parameters(), w):
+            p.copy_(torch.tensor(a))
+    return det
+
+
+# ---------------------------------------------------------------- a2: one ACS stage vs golden G1
+@pytest.mark.parametrize("S", [2, 4, 8, 16, 256])
+@pytest.mark.parametrize("B", [1, 3, 64])
+def test_acs_block_golden(golden, dev, S, B):
+    g = golden("g1_acs_block")
+    out, j = mvn.acs_block(torch.tensor(g[f"in_S{S}_B{B}"], device=dev), torch.tensor(g[f"llr_S{S}_B{B}"], device=dev),
+                           None, S)
+    assert np.array_equal(_np(out), g[f"out_S{S}_B{B}"])
+    assert np.array_equal(_np(j), g[f"argj_S{S}_B{B}"])
+
+
+# ---------------------------------------------------------------- a3-a5: VA vs golden G2
+@pytest.mark.parametrize("name", ["L4_static", "L4_fading1", "L4_fading2", "L4_cost2100", "L2_static", "L3_static",
+                                  "L8_static", "L4_config1"])
+def test_va_golden(golden, dev, name):
+    g = golden("g2_va")
+    L, frames, sub, T, snr, fdec, ttype = [int(v) for v in g[f"{name}_meta"]]
+    S = 2 ** L
+    det = mvn.VADetector(S, L, T, frames * sub, "ISI_AWGN", 0, bool(fdec), ttype,
+                         {"train": "time_decay", "val": str(g[f"{name}_coef"])})
+    y = torch.tensor(g[f"{name}_rx"], device=dev)
+    tx = torch.tensor(g[f"{name}_tx"].astype(np.float32), device=dev)
+    dec = det(y, "val", snr, 0.2)
+    assert dec.dtype == torch.float32 and dec.shape == y.shape and dec.device == y.device
+    assert np.array_equal(_np(dec), g[f"{name}_decoded"].astype(np.float32))
+    # final path metrics through the raw ABI
+    pri = torch.tensor(np.ascontiguousarray(g[f"{name}_state_priors"].T), device=dev)
+    d2 = torch.zeros_like(y)
+    fm = torch.empty(y.shape[0], S, device=dev)
+    rc = mvn._lib.load().mvn_va_decode_f32(mvn._lib.ptr(y), y.shape[1], mvn._lib.ptr(pri), pri.shape[0],
+                                           mvn._lib.ptr(d2), y.shape[1], mvn._lib.ptr(fm), y.shape[0], T, S,
+                                           mvn._lib.current_stream(dev))
+    assert rc == 0
+    assert np.array_equal(_np(fm), g[f"{name}_final"]) and torch.equal(d2, dec)
+    # sweep over the reference-order materialised costs gives the same decisions
+    cost = det.compute_likelihood_priors(y, snr, 0.2, "val")
+    dec3, fm3 = mvn.acs_sweep(cost, return_final=True)
+    assert torch.equal(dec3, dec) and np.array_equal(_np(fm3), g[f"{name}_final"])
+    # a10/a11: error rates on data rows, as single_eval_at_point
+    rows = torch.tensor(g[f"{name}_data_indices"], device=dev)
+    ser, fer, counters = mvn.single_eval_at_point(det, tx, y, snr, 0.2, rows)
+    assert ser == pytest.approx(g[f"{name}_rates"][0], rel=1e-6, abs=1e-7)  # reference: fp32 mean
+    assert fer == pytest.approx(g[f"{name}_rates"][1], rel=1e-6, abs=1e-7)
+    s2, f2, idx = mvn.calculate_error_rates(dec[rows], tx[rows])
+    assert (s2, f2) == (ser, fer) and np.array_equal(_np(idx), g[f"{name}_err_idx"])
+
+
+@pytest.mark.parametrize("name", ["L4_fading1", "L4_cost2100"])
+def test_va_by_word_count(golden, dev, name):
+    g = golden("g2_va")
+    L, frames, sub, T, snr, fdec, ttype = [int(v) for v in g[f"{name}_meta"]]
+    det = mvn.VADetector(2 ** L, L, T, frames * sub, "ISI_AWGN", 0, bool(fdec), ttype,
+                         {"train": "time_decay", "val": str(g[f"{name}_coef"])})
+    y = torch.tensor(g[f"{name}_rx"], device=dev)
+    dec = det(y[7].reshape(1, -1), "val", snr, 0.2, 7)
+    assert np.array_equal(_np(dec), g[f"{name}_count7_decoded"].astype(np.float32))
+
+
+# ---------------------------------------------------------------- a6-a8: ViterbiNet vs golden G3/G4
+VNET_EXACT = ["S16_init_exact", "S16_trained_exact", "S4_trained_exact", "S256_init_exact", "S2_init_exact"]
+
+
+@pytest.mark.parametrize("name", VNET_EXACT)
+def test_vnet_golden_bit_exact(golden, dev, name):
+    g = golden("g3_vnet")
+    S, B, T, _ = [int(v) for v in g[f"{name}_meta"]]
+    w = [g[f"{name}_w{i}"] for i in range(6)]
+    det = _vnet_with(w, S, T, dev)
+    y = torch.tensor(g[f"{name}_y"], device=dev)
+    dec = det(y, "val")
+    assert np.array_equal(_np(dec), g[f"{name}_decoded"].astype(np.float32))
+    assert np.array_equal(_np(det.logits(y)), g[f"{name}_logits"])  # logits bit-exact vs the reference
+    meta = mvn.META_VNETDetector(S, {"train": T, "val": T})
+    assert torch.equal(meta(y, "val", list(det.parameters())), dec)  # a8
+    d2, lg2 = mvn.detectors._vnet_val(y, list(det.parameters()), S, T, return_logits=True)
+    assert torch.equal(d2, dec) and np.array_equal(_np(lg2), g[f"{name}_logits"])
+
+
+@pytest.mark.parametrize("name", ["S16_trained_mt", "S16_trained_odd"])
+def test_vnet_scalar_tail_tolerance(golden, dev, name):
+    """torch-CPU's scalar sigmoid tail (see tests/test_oracle_golden.py): |dlogit| <= 2e-6 on <= 0.1 % of
+    the logits; decisions identical."""
+    g = golden("g3_vnet")
+    S, B, T, _ = [int(v) for v in g[f"{name}_meta"]]
+    det = _vnet_with([g[f"{name}_w{i}"] for i in range(6)], S, T, dev)
+    y = torch.tensor(g[f"{name}_y"], device=dev)
+    lg = _np(det.logits(y))
+    ref = g[f"{name}_logits"]
+    assert np.max(np.abs(lg - ref)) <= 2e-6 and np.count_nonzero(lg != ref) <= 1e-3 * ref.size
+    assert np.array_equal(_np(det(y, "val")), g[f"{name}_decoded"].astype(np.float32))
+
+
+@pytest.mark.parametrize("coef", ["time_decay", "cost2100"])
+def test_by_word_golden(golden, dev, coef):
+    """a12: the 300 sequential B=1,T=136 detector calls of eval_by_word, batched and one by one."""
+    g = golden("g7_by_word")
+    det = _vnet_with([g[f"w{i}"] for i in range(6)], 16, 136, dev)
+    y = torch.tensor(g[f"{coef}_y"], device=dev)
+    ref = g[f"{coef}_detected"].astype(np.float32)
+    assert np.array_equal(_np(mvn.detect_by_word(det, y, 10, 0.2, batched=True)), ref)
+    assert np.array_equal(_np(mvn.detect_by_word(det, y[:40], 10, 0.2, batched=False)), ref[:40])
+
+
+# ---------------------------------------------------------------- HIP vs oracle on seeded inputs
+def _rand_weights(S, rng, scale=1.0):
+    return [(rng.uniform(-1, 1, (100, 1)) * scale).astype(np.float32), rng.uniform(-1, 1, 100).astype(np.float32),
+            rng.uniform(-0.1, 0.1, (50, 100)).astype(np.float32), rng.uniform(-0.1, 0.1, 50).astype(np.float32),
+            rng.uniform(-0.14, 0.14, (S, 50)).astype(np.float32), rng.uniform(-0.14, 0.14, S).astype(np.float32)]
+
+
+@pytest.mark.parametrize("S", [2, 4, 8, 16, 32, 64, 128, 256])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 7), (5, 64), (67, 129), (130, 33)])
+def test_sweep_vs_oracle(oracle, dev, S, B, T):
+    rng = np.random.RandomState(S * 1000 + B * 10 + T)
+    cost = rng.normal(0, 2, (B, T, S)).astype(np.float32)
+    if B > 2:
+        cost[1] = 0.25  # all-equal costs: every comparison ties
+        cost[2, :, ::2] = cost[2, :, 1::2]
+    dec, fm = mvn.acs_sweep(torch.tensor(cost, device=dev), return_final=True)
+    rdec, rfm = oracle.acs_sweep(cost)
+    assert np.array_equal(_np(dec), rdec) and np.array_equal(_np(fm), rfm)
+
+
+@pytest.mark.parametrize("S", [2, 4, 8, 16, 32, 64, 128, 256])
+@pytest.mark.parametrize("B,T,Bp", [(1, 5, 1), (6, 40, 3), (64, 136, 64), (131, 257, 1)])
+def test_va_vs_oracle(oracle, dev, S, B, T, Bp):
+    rng = np.random.RandomState(S + B + T)
+    y = rng.normal(0, 1.5, (B, T + 3)).astype(np.float32)  # row stride > T (Q5: loop bound is the ctor's T)
+    if B > 1:
+        y[1] = 0.0  # symmetric priors + zero input: systematic ties (Q2)
+    pri = rng.normal(0, 1, (Bp, S)).astype(np.float32)
+    pri[0] = np.concatenate([np.linspace(-2, 2, S // 2), -np.linspace(-2, 2, S // 2)]).astype(np.float32)
+    yt, pt = torch.tensor(y, device=dev), torch.tensor(pri, device=dev)
+    dec = torch.zeros_like(yt)
+    fm = torch.empty(B, S, device=dev)
+    rc = mvn._lib.load().mvn_va_decode_f32(mvn._lib.ptr(yt), T + 3, mvn._lib.ptr(pt), Bp, mvn._lib.ptr(dec), T + 3,
+                                           mvn._lib.ptr(fm), B, T, S, mvn._lib.current_stream(dev))
+    assert rc == 0
+    rdec, rfm = oracle.va_decode(y, pri, T=T)
+    assert np.array_equal(_np(dec), rdec) and np.array_equal(_np(fm), rfm)
+    assert np.all(_np(dec)[:, T:] == 0) and np.all(_np(dec)[:, 0] == 0)  # untouched tail, quirk Q1
+
+
+@pytest.mark.parametrize("S", [2, 4, 8, 16, 32, 64, 128, 256])
+@pytest.mark.parametrize("B,T", [(1, 1), (2, 9), (9, 136), (33, 65)])
+def test_vnet_vs_oracle(oracle, dev, S, B, T):
+    rng = np.random.RandomState(7 * S + B + T)
+    w = _rand_weights(S, rng, scale=3.0 if B == 9 else 1.0)
+    y = rng.normal(0, 2, (B, T)).astype(np.float32)
+    y[0, 0] = 0.0
+    if T > 4:
+        y[0, 1:4] = [60.0, -60.0, 1e4]  # saturating sigmoids (exp overflow / underflow paths)
+    det = _vnet_with(w, S, T, dev)
+    yt = torch.tensor(y, device=dev)
+    dec, lg = mvn.detectors._vnet_val(yt, list(det.parameters()), S, T, return_logits=True)
+    rdec, rlg = oracle.vnet_decode(y, w, want_logits=True)
+    assert np.array_equal(_np(lg), rlg)
+    assert np.array_equal(_np(dec), rdec)
+    assert np.array_equal(_np(det(yt, "val")), rdec)  # workspace path
+    assert np.array_equal(_np(det.logits(yt)), rlg)
+
+
+def test_vnet_workspace_slicing(oracle, dev):
+    """A workspace that only fits 3 blocks forces the sliced path; results unchanged."""
+    S, B, T = 16, 11, 50
+    rng = np.random.RandomState(3)
+    w = _rand_weights(S, rng)
+    y = rng.normal(0, 1, (B, T)).astype(np.float32)
+    yt = torch.tensor(y, device=dev)
+    wt = _weights_t(w, dev)
+    dec = torch.zeros_like(yt)
+    fm = torch.empty(B, S, device=dev)
+    ws = torch.empty(3 * T * S * 4 + 100, dtype=torch.uint8, device=dev)
+    lib = mvn._lib.load()
+    rc = lib.mvn_vnet_decode_f32(mvn._lib.ptr(yt), T, *[mvn._lib.ptr(t) for t in wt], mvn._lib.ptr(dec), T, None,
+                                 mvn._lib.ptr(fm), mvn._lib.ptr(ws), ws.numel(), B, T, S, mvn._lib.current_stream(dev))
+    assert rc == 0
+    rdec, rfm = oracle.vnet_decode(y, w, want_final=True)
+    assert np.array_equal(_np(dec), rdec) and np.array_equal(_np(fm), rfm)
+    rc = lib.mvn_vnet_decode_f32(mvn._lib.ptr(yt), T, *[mvn._lib.ptr(t) for t in wt], mvn._lib.ptr(dec), T, None,
+                                 None, mvn._lib.ptr(ws), 16, B, T, S, mvn._lib.current_stream(dev))
+    assert rc == -5  # MVN_E_WORKSPACE
+
+
+def test_count_errors_vs_oracle(oracle, dev):
+    rng = np.random.RandomState(9)
+    for (N, K) in [(1, 1), (7, 30), (300, 136), (1000, 1000)]:
+        dec = rng.randint(0, 2, (N, K + 5)).astype(np.float32)
+        tx = dec[:, :K].copy()
+        flips = rng.rand(N, K) < 0.01
+        tx[flips] = 1 - tx[flips]
+        rows = np.sort(rng.choice(N, size=max(1, N // 2), replace=False)).astype(np.int64)
+        d, t = torch.tensor(dec, device=dev), torch.tensor(tx, device=dev)
+        got = mvn.count_errors(d[:, :K], t, torch.tensor(rows, device=dev))
+        assert got.tolist() == oracle.count_errors(dec[:, :K], tx, rows).tolist()
+        got_all = mvn.count_errors(d[:, :K], t)
+        assert got_all.tolist() == oracle.count_errors(dec[:, :K], tx).tolist()
+
+
+def test_detector_api_contract(dev):
+    """Shapes/dtypes/exceptions a trainer relies on."""
+    det = mvn.VNETDetector(16, {"train": 20, "val": 20}).to(dev)
+    y = torch.randn(4, 24, device=dev)
+    out = det(y, "val", 10, 0.2)
+    assert out.shape == y.shape and out.dtype == torch.float32 and torch.all(out[:, 20:] == 0)
+    assert set(torch.unique(out).tolist()) <= {0.0, 1.0}
+    out.cpu().numpy()  # trainer.py:235
+    lg = det(y, "train")
+    assert lg.shape == (4, 24, 16) and lg.requires_grad
+    with pytest.raises(IndexError):
+        mvn.VNETDetector(16, {"train": 30, "val": 30}).to(dev)(y, "val")
+    # weights are read at call time: an in-place update changes the next decode (python_utils.py:17-27)
+    with torch.no_grad():
+        before = det(y, "val").clone()
+        for p in det.parameters():
+            p.data[:] = torch.randn_like(p)
+        after = det(y, "val")
+    assert not torch.equal(before, after)
+    va = mvn.VADetector(16, 4, 24, 3, "ISI_AWGN", 0, False, 1, CC)
+    with pytest.raises(RuntimeError):
+        va(y, "val", 10, 0.2)  # 4 rows, 3 channel rows: the reference's broadcast fails too
+    assert va(y[:3], "val", 10, 0.2).shape == (3, 24)
+    assert va(torch.empty(0, 24, device=dev), "val", 10, 0.2).shape == (0, 24)
+
+
+# ---------------------------------------------------------------- full BASELINE sizes
+def test_config1_va_full_size_vs_oracle(oracle, dev):
+    """BASELINE config 1: VA, L=4, 100 blocks x 1000 symbols."""
+    tx, y = mvn.synthetic_words(100, 1000, 4, 10.0, 0.2, dev, seed=3450002)
+    va = mvn.VADetector(16, 4, 1000, 1, "ISI_AWGN", 0, False, 1, CC)
+    dec = va(y, "val", 10.0, 0.2)
+    pri = _np(va.compute_state_priors(mvn.estimate_channel(4, 0.2, "time_decay"))).T.copy()
+    assert np.array_equal(_np(dec), oracle.va_decode(_np(y), pri, want_final=False))
+    ser, fer, c = mvn.single_eval_at_point(va, tx, y, 10.0, 0.2)
+    assert c.tolist()[1] == 100 * 1000 and 0 < ser < 0.02
+
+
+def test_config2_vnet_full_size(golden, oracle, dev):
+    """BASELINE config 2: ViterbiNet L=4, 10 000 blocks x 1000 symbols, with the trained golden weights.
+    Full-size oracle comparison on a 512-block sample + size-independent properties on all 10^7 symbols:
+    block independence (any sub-batch decodes identically) and row-permutation equivariance."""
+    g = golden("g7_by_word")
+    w = [g[f"w{i}"] for i in range(6)]
+    B, T = 10000, 1000
+    tx, y = mvn.synthetic_words(B, T, 4, 10.0, 0.2, dev, seed=3450002)
+    det = _vnet_with(w, 16, T, dev)
+    dec = det(y, "val")
+    idx = torch.arange(0, B, 20, device=dev)[:512]
+    assert np.array_equal(_np(dec[idx]), oracle.vnet_decode(_np(y[idx]), w))
+    assert torch.equal(det(y[1234:1300], "val"), dec[1234:1300])
+    perm = torch.randperm(B, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    assert torch.equal(det(y[perm], "val"), dec[perm])
+    ser, fer, c = mvn.single_eval_at_point(det, tx, y, 10.0, 0.2)
+    assert c.tolist()[1] == B * T and 0 < ser < 0.05  # trained weights: a sane SER at 10 dB
+    assert torch.all(dec[:, 0] == 0)  # Q1

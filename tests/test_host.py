@@ -1,0 +1,119 @@
+"""CPU-only: host-side mirror of the reference interface (channel taps, state priors, labels, 'train'
+phase, exceptions, sharding arithmetic) against the golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+import meta_viterbinet_amd as mvn
+
+CC = {"train": "time_decay", "val": "time_decay"}
+
+
+def test_estimate_channel_tables(golden):
+    g = golden("g6_channels")
+    got = np.concatenate([mvn.estimate_channel(4, 0.2, "cost2100", index=i) for i in range(300)])
+    assert np.array_equal(got, g["cost2100"])
+    assert got[0].tolist() == pytest.approx([1, 0.44173482, 0.29808132, 0.04954621], rel=1e-7)
+    for ttype in (1, 2):
+        got = np.concatenate([mvn.estimate_channel(4, 0.2, "time_decay", fading=True, index=i, fading_taps_type=ttype)
+                              for i in range(300)])
+        assert np.array_equal(got, g[f"time_decay_fading{ttype}"])
+    for L in (2, 3, 4, 8):
+        assert np.array_equal(mvn.estimate_channel(L, 0.2, "time_decay"), g[f"time_decay_L{L}"])
+    assert np.array_equal(mvn.estimate_channel(4, 0.5, "time_decay"), g["time_decay_gamma05"])
+    with pytest.raises(ValueError):
+        mvn.estimate_channel(4, 0.2, "nope")
+    with pytest.raises(ValueError):
+        mvn.estimate_channel(4, 0.2, "time_decay", fading=True, fading_taps_type=3)
+    with pytest.raises(ValueError):  # fading hard-codes 4 taps
+        mvn.estimate_channel(8, 0.2, "time_decay", fading=True)
+
+
+@pytest.mark.parametrize("name", ["L4_static", "L4_fading1", "L4_fading2", "L4_cost2100", "L2_static", "L3_static",
+                                  "L8_static"])
+def test_state_priors_match_reference(golden, name):
+    g = golden("g2_va")
+    L, frames, sub, T, snr, fdec, ttype = [int(v) for v in g[f"{name}_meta"]]
+    coef = str(g[f"{name}_coef"])
+    det = mvn.VADetector(2 ** L, L, T, frames * sub, "ISI_AWGN", 0, bool(fdec), ttype,
+                         {"train": "time_decay", "val": coef})
+    h = det._estimate_all(0.2, "val")
+    assert np.array_equal(h, g[f"{name}_h"])
+    pri = det.compute_state_priors(h)
+    assert pri.dtype == torch.float32 and tuple(pri.shape) == (2 ** L, frames * sub)
+    assert np.array_equal(pri.cpu().numpy(), g[f"{name}_state_priors"])
+    assert np.array_equal(mvn.data_indices(frames, sub).numpy(), g[f"{name}_data_indices"])
+    # materialised costs (API-parity helper) are the reference's, bit for bit (torch CPU both sides)
+    y = torch.tensor(g[f"{name}_rx"])
+    head = g[f"{name}_cost_head"]
+    cost = det.compute_likelihood_priors(y, snr, 0.2, "val")
+    assert np.array_equal(cost[: head.shape[0], :8].numpy(), head)
+
+
+def test_va_errors():
+    det = mvn.VADetector(16, 4, 8, 1, "ISI_AWGN", 0, False, 1, CC)
+    with pytest.raises(NotImplementedError):
+        det(torch.zeros(1, 8), "train")
+    bad = mvn.VADetector(16, 4, 8, 1, "OTHER", 0, False, 1, CC)
+    with pytest.raises(Exception, match="No such channel defined"):
+        bad.compute_state_priors(np.ones((1, 4)))
+    assert det.transition_table_array.tolist() == [[(2 * s) % 16, (2 * s + 1) % 16] for s in range(16)]
+    assert det.transition_table.dtype == torch.float32  # kept as a float tensor like the reference (:40)
+
+
+def test_transition_table(golden):
+    g = golden("g1_acs_block")
+    for S in (2, 4, 8, 16, 256):
+        assert np.array_equal(mvn.create_transition_table(S), g[f"table_S{S}"])
+
+
+def test_calculate_states(golden):
+    g = golden("g5_kats")
+    assert mvn.calculate_states(4, torch.tensor(g["states_kat_in"])).tolist() == [13, 6, 3, 9, 4, 2, 1]
+    for L in (2, 3, 4, 8):
+        got = mvn.calculate_states(L, torch.tensor(g[f"states_L{L}_in"]))
+        assert got.dtype == torch.int64 and np.array_equal(got.numpy(), g[f"states_L{L}_out"])
+
+
+@pytest.mark.parametrize("name", ["S16_trained_exact", "S4_trained_exact", "S256_init_exact"])
+def test_vnet_train_phase_and_checkpoint_keys(golden, name):
+    """'train' phase = plain torch with autograd; parameter names/order as the reference (a6)."""
+    g = golden("g3_vnet")
+    S, B, T, _ = [int(v) for v in g[f"{name}_meta"]]
+    torch.set_num_threads(1)
+    det = mvn.VNETDetector(S, {"train": T, "val": T}).to("cpu")
+    keys = list(det.state_dict().keys())
+    assert keys == [str(k) for k in g["state_dict_keys"]]
+    sd = {k: torch.tensor(g[f"{name}_w{i}"]) for i, k in enumerate(keys)}
+    det.load_state_dict(sd)
+    assert [tuple(p.shape) for p in det.parameters()] == [(100, 1), (100,), (50, 100), (50,), (S, 50), (S,)]
+    y = torch.tensor(g[f"{name}_y"])
+    logits = det(y, "train")
+    assert logits.requires_grad and tuple(logits.shape) == (B, T, S)
+    assert np.array_equal(logits.detach().numpy(), g[f"{name}_logits"])
+    meta = mvn.META_VNETDetector(S, {"train": T, "val": T})
+    assert len(list(meta.parameters())) == 0
+    lm = meta(y, "train", list(det.parameters()))
+    assert torch.equal(lm, logits)
+    g0 = torch.autograd.grad(lm.sum(), list(det.parameters()))  # MAML differentiates through var
+    assert all(t is not None for t in g0)
+    import copy
+
+    clone = copy.deepcopy(det)  # trainer.py:275
+    assert torch.equal(clone(y, "train"), logits)
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 100, 10000, 10001):
+        for world in (1, 2, 3, 4, 8):
+            spans = [mvn.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_rates_from_counters():
+    assert mvn.rates_from_counters(torch.tensor([3, 100, 1, 4])) == (0.03, 0.25)
+    ser, fer = mvn.rates_from_counters(torch.tensor([0, 0, 0, 0]))
+    assert np.isnan(ser) and np.isnan(fer)
