@@ -13,6 +13,7 @@
 //   count_errors_kernel    metrics.py:7-17 as int64 counters.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mvn.h"
 
@@ -366,6 +367,8 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
     return (int)hipGetLastError();
 }
 
+#include "vnet16_fused.inc"
+
 // -------------------------------------------------------------------------------------------
 // metrics.py:7-17 as integer counters.  One wave per row, block-level reduction, one atomic
 // per workgroup per counter.
@@ -422,6 +425,12 @@ __global__ __launch_bounds__(256) void acs_block_kernel(const float *__restrict_
     const bool second = v1 < v0;  // first minimal index wins
     out[e] = second ? v1 : v0;
     if (argmin_j) argmin_j[e] = second ? 1 : 0;
+}
+
+// MVN_UNFUSED=1 forces the two-kernel ViterbiNet path (MLP -> logits -> sweep) for testing.
+bool unfused_forced() {
+    const char *e = getenv("MVN_UNFUSED");
+    return e && e[0] == '1';
 }
 
 bool valid_states(int S) { return S >= 2 && S <= 256 && (S & (S - 1)) == 0; }
@@ -528,6 +537,16 @@ int mvn_vnet_decode_f32(const float *y, int64_t y_ld, const float *W1, const flo
     if (B == 0 || T == 0) return MVN_OK;
     if (!y || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !dec) return MVN_E_NULL;
     hipStream_t st = (hipStream_t)stream;
+    if (S == 16 && !unfused_forced()) {  // fused single-kernel path: no scratch, 8 B/symbol of HBM traffic
+        const unsigned grid = (unsigned)((B + kFusedWaves - 1) / kFusedWaves);
+        if (logits_out)
+            hipLaunchKernelGGL((vnet16_fused_kernel<true>), dim3(grid), dim3(64 * kFusedWaves), 0, st, y, y_ld, W1,
+                               b1, W2, b2, W3, b3, dec, dec_ld, logits_out, final_metric, B, T);
+        else
+            hipLaunchKernelGGL((vnet16_fused_kernel<false>), dim3(grid), dim3(64 * kFusedWaves), 0, st, y, y_ld, W1,
+                               b1, W2, b2, W3, b3, dec, dec_ld, logits_out, final_metric, B, T);
+        return (int)hipGetLastError();
+    }
     const size_t per_block = (size_t)T * (size_t)S * sizeof(float);
     int64_t slice = B;
     float *buf = logits_out;

@@ -204,8 +204,40 @@ def test_vnet_vs_oracle(oracle, dev, S, B, T):
     assert np.array_equal(_np(det.logits(yt)), rlg)
 
 
-def test_vnet_workspace_slicing(oracle, dev):
+@pytest.mark.parametrize("B,T", [(4, 16), (5, 17), (300, 136), (257, 1000), (64, 31)])
+def test_vnet16_fused_and_unfused_paths(oracle, dev, monkeypatch, B, T):
+    """S=16 runs the fused single-kernel path by default; MVN_UNFUSED=1 forces MLP -> logits -> sweep.
+    Both must equal the oracle bit for bit (decisions, logits, final path metrics), including tiles
+    that take the slow (saturating) sigmoid path."""
+    S = 16
+    rng = np.random.RandomState(B * 7 + T)
+    w = _rand_weights(S, rng, scale=2.0)
+    y = rng.normal(0, 2, (B, T)).astype(np.float32)
+    y[B // 2, T // 2] = 70.0  # one tile of one block leaves the fast-sigmoid range
+    yt = torch.tensor(y, device=dev)
+    wt = _weights_t(w, dev)
+    rdec, rlg, rfm = oracle.vnet_decode(y, w, want_logits=True, want_final=True)
+    lib = mvn._lib.load()
+    ws = torch.empty(B * T * S * 4, dtype=torch.uint8, device=dev)
+    for unfused in ("0", "1"):
+        monkeypatch.setenv("MVN_UNFUSED", unfused)
+        for want_logits in (False, True):
+            dec = torch.zeros_like(yt)
+            fm = torch.empty(B, S, device=dev)
+            lg = torch.empty(B, T, S, device=dev) if want_logits else None
+            rc = lib.mvn_vnet_decode_f32(mvn._lib.ptr(yt), T, *[mvn._lib.ptr(t) for t in wt], mvn._lib.ptr(dec), T,
+                                         mvn._lib.ptr(lg), mvn._lib.ptr(fm), mvn._lib.ptr(ws), ws.numel(), B, T, S,
+                                         mvn._lib.current_stream(dev))
+            assert rc == 0
+            assert np.array_equal(_np(dec), rdec), (unfused, want_logits)
+            assert np.array_equal(_np(fm), rfm), (unfused, want_logits)
+            if want_logits:
+                assert np.array_equal(_np(lg), rlg)
+
+
+def test_vnet_workspace_slicing(oracle, dev, monkeypatch):
     """A workspace that only fits 3 blocks forces the sliced path; results unchanged."""
+    monkeypatch.setenv("MVN_UNFUSED", "1")  # the sliced scratch path only exists on the two-kernel route
     S, B, T = 16, 11, 50
     rng = np.random.RandomState(3)
     w = _rand_weights(S, rng)
