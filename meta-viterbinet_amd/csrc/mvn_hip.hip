@@ -368,6 +368,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 }
 
 #include "vnet16_fused.inc"
+#include "sweep16_rows.inc"
 
 // -------------------------------------------------------------------------------------------
 // metrics.py:7-17 as integer counters.  One wave per row, block-level reduction, one atomic
@@ -433,6 +434,20 @@ bool unfused_forced() {
     return e && e[0] == '1';
 }
 
+// MVN_GENERIC_SWEEP=1 forces the generic state-per-lane LDS sweep at S=16 (testing).
+bool generic_sweep_forced() {
+    const char *e = getenv("MVN_GENERIC_SWEEP");
+    return e && e[0] == '1';
+}
+
+template <int MODE>
+int dispatch_sweep(const float *src, int64_t src_ld, const float *priors, int64_t Bp, float *dec, int64_t dec_ld,
+                   float *final_metric, int64_t B, int T, int S, hipStream_t st) {
+    if (S == 16 && !generic_sweep_forced())
+        return launch_sweep16_rows<MODE>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
+    return launch_sweep<MODE>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, S, st);
+}
+
 bool valid_states(int S) { return S >= 2 && S <= 256 && (S & (S - 1)) == 0; }
 
 }  // namespace
@@ -496,7 +511,7 @@ int mvn_acs_sweep_f32(const float *cost, float *dec, int64_t dec_ld, float *fina
     if (!valid_states(S)) return MVN_E_STATES;
     if (B == 0 || T == 0) return MVN_OK;
     if (!cost || !dec) return MVN_E_NULL;
-    return launch_sweep<MODE_COST>(cost, 0, nullptr, 1, dec, dec_ld, final_metric, B, T, S,
+    return dispatch_sweep<MODE_COST>(cost, 0, nullptr, 1, dec, dec_ld, final_metric, B, T, S,
                                    (hipStream_t)stream);
 }
 
@@ -508,7 +523,7 @@ int mvn_va_decode_f32(const float *y, int64_t y_ld, const float *state_priors, i
     if (Bp < 1 || (B % Bp) != 0) return MVN_E_PRIORS;
     if (B == 0 || T == 0) return MVN_OK;
     if (!y || !state_priors || !dec) return MVN_E_NULL;
-    return launch_sweep<MODE_VA>(y, y_ld, state_priors, Bp, dec, dec_ld, final_metric, B, T, S,
+    return dispatch_sweep<MODE_VA>(y, y_ld, state_priors, Bp, dec, dec_ld, final_metric, B, T, S,
                                  (hipStream_t)stream);
 }
 
@@ -562,7 +577,7 @@ int mvn_vnet_decode_f32(const float *y, int64_t y_ld, const float *W1, const flo
         float *lg = logits_out ? logits_out + (size_t)b0 * T * S : buf;
         int rc = launch_mlp(y + b0 * y_ld, y_ld, T, nb * T, W1, b1, W2, b2, W3, b3, lg, S, st);
         if (rc) return rc;
-        rc = launch_sweep<MODE_NEGLOGIT>(lg, 0, nullptr, 1, dec + b0 * dec_ld, dec_ld,
+        rc = dispatch_sweep<MODE_NEGLOGIT>(lg, 0, nullptr, 1, dec + b0 * dec_ld, dec_ld,
                                          final_metric ? final_metric + b0 * S : nullptr, nb, T, S, st);
         if (rc) return rc;
     }

@@ -235,6 +235,31 @@ def test_vnet16_fused_and_unfused_paths(oracle, dev, monkeypatch, B, T):
                 assert np.array_equal(_np(lg), rlg)
 
 
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 15), (4, 16), (5, 17), (67, 129), (130, 1000)])
+def test_sweep16_rows_and_generic_paths(oracle, dev, monkeypatch, B, T):
+    """S=16 has a dedicated row-per-block DPP sweep; MVN_GENERIC_SWEEP=1 forces the generic LDS sweep.
+    Sweep over costs and fused VA must both match the oracle on either path."""
+    S = 16
+    rng = np.random.RandomState(B + 31 * T)
+    cost = rng.normal(0, 2, (B, T, S)).astype(np.float32)
+    cost[0, :, :] = np.round(cost[0, :, :])  # small integers: many exact ties between states
+    y = rng.normal(0, 1.5, (B, T)).astype(np.float32)
+    pri = rng.normal(0, 1, (1, S)).astype(np.float32)
+    rdec, rfm = oracle.acs_sweep(cost)
+    vdec, vfm = oracle.va_decode(y, pri)
+    ct, yt, pt = torch.tensor(cost, device=dev), torch.tensor(y, device=dev), torch.tensor(pri, device=dev)
+    for generic in ("0", "1"):
+        monkeypatch.setenv("MVN_GENERIC_SWEEP", generic)
+        dec, fm = mvn.acs_sweep(ct, return_final=True)
+        assert np.array_equal(_np(dec), rdec) and np.array_equal(_np(fm), rfm), generic
+        d2 = torch.zeros_like(yt)
+        f2 = torch.empty(B, S, device=dev)
+        rc = mvn._lib.load().mvn_va_decode_f32(mvn._lib.ptr(yt), T, mvn._lib.ptr(pt), 1, mvn._lib.ptr(d2), T,
+                                               mvn._lib.ptr(f2), B, T, S, mvn._lib.current_stream(dev))
+        assert rc == 0
+        assert np.array_equal(_np(d2), vdec) and np.array_equal(_np(f2), vfm), generic
+
+
 def test_vnet_workspace_slicing(oracle, dev, monkeypatch):
     """A workspace that only fits 3 blocks forces the sliced path; results unchanged."""
     monkeypatch.setenv("MVN_UNFUSED", "1")  # the sliced scratch path only exists on the two-kernel route
