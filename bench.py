@@ -39,6 +39,19 @@ def golden_weights(device):
     return [torch.tensor(g[f"w{i}"], device=device) for i in range(6)]
 
 
+def measured_traffic(kernel, B):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, collected with
+    tools/pmc_traffic.sh on this same command); None when the workload differs from the profiled one."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        w = t["workload"]
+        if (w["blocks"], w["block_length"], w["n_states"]) == (B, T, S):
+            return t[kernel]["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def event_time_ms(fn, iters, stream_device):
     """Average duration of fn() measured with HIP events on the stream the kernels are launched on
     (the ABI is called with torch's current stream, so torch.cuda.Event brackets exactly those launches)."""
@@ -170,11 +183,16 @@ def main():
             "fer_at_snr": fer,
             "roofline": {"kernel": "vnet16_fused_kernel<false> (ViterbiNet MLP on f32 MFMA 16x16x4 + in-place DPP trellis sweep)", "bound": "mfma",
                          "achieved": mlp_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": mlp_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": mlp_tflops / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": measured_traffic("vnet16_fused_kernel<false>", B), "traffic_unit": "HBM bytes/launch",
+                         "algorithmic_hbm_bytes": 8.0 * B * T,
                          "ms_per_launch": ms_fused, "flop_per_symbol": FLOP_PER_SYMBOL},
             "roofline_acs_sweep": {"kernel": "sweep16_rows_kernel<COST> (mvn_acs_sweep_f32)", "bound": "hbm",
                                    "achieved": acs_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                   "frac": acs_gbps / PEAK_HBM_GBPS, "traffic": None, "ms_per_launch": ms_acs,
+                                   "frac": acs_gbps / PEAK_HBM_GBPS,
+                                   "traffic": measured_traffic("sweep16_rows_kernel<0>", B),
+                                   "traffic_unit": "HBM bytes/launch", "algorithmic_hbm_bytes": ACS_BYTES_PER_SYMBOL * B * T,
+                                   "ms_per_launch": ms_acs,
                                    "bytes_per_symbol": ACS_BYTES_PER_SYMBOL},
             "ms_per_step_events": ms_step,
         }
