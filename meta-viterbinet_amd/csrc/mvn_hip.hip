@@ -19,6 +19,8 @@
 
 namespace {
 
+constexpr bool kFusedLdsDefault = true;
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -434,6 +436,42 @@ bool unfused_forced() {
     return e && e[0] == '1';
 }
 
+// MVN_FUSED_LDSW=0/1 selects the register- or LDS-resident weight variant of the fused kernel.
+bool fused_lds_weights() {
+    const char *e = getenv("MVN_FUSED_LDSW");
+    return e ? e[0] == '1' : kFusedLdsDefault;
+}
+
+// Residency choice for the LDS-weights fused kernel.  One wave owns one block for all T symbols, so the
+// kernel's makespan is ceil(B / resident_waves) wave lifetimes: pick the workgroups/CU (3..5, i.e. 12..20
+// waves/CU) whose slot count divides B best, and enforce it by padding the launch's dynamic LDS.
+// MVN_FUSED_WGS_PER_CU=n overrides.
+unsigned fused_dynamic_lds_pad(int64_t B) {
+    constexpr int kStaticLds = 29728;      // ldsA2 + ldsWB + ldsB3w (see -Rpass-analysis)
+    constexpr int kLdsPerCu = 160 * 1024;  // gfx950
+    int best = 5;
+    const char *e = getenv("MVN_FUSED_WGS_PER_CU");
+    if (e && e[0] >= '1' && e[0] <= '5') {
+        best = e[0] - '0';
+    } else {
+        double best_score = 0.0;
+        for (int w = 3; w <= 5; ++w) {
+            const double slots = 256.0 * w * kFusedWavesLds;
+            const double rounds = (double)B / slots;
+            const double eff = rounds / (double)(int64_t)(rounds + 0.999999);
+            const double rate = w == 3 ? 0.93 : w == 4 ? 0.98 : 1.0;  // measured relative SIMD throughput
+            if (eff * rate > best_score) {
+                best_score = eff * rate;
+                best = w;
+            }
+        }
+    }
+    if (best >= 5) return 0;
+    const int per_wg = kLdsPerCu / best;        // at most `best` workgroups fit
+    const int need = per_wg - kStaticLds - 512;  // keep (best+1) from fitting
+    return need > 0 ? (unsigned)need : 0;
+}
+
 // MVN_GENERIC_SWEEP=1 forces the generic state-per-lane LDS sweep at S=16 (testing).
 bool generic_sweep_forced() {
     const char *e = getenv("MVN_GENERIC_SWEEP");
@@ -553,13 +591,19 @@ int mvn_vnet_decode_f32(const float *y, int64_t y_ld, const float *W1, const flo
     if (!y || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !dec) return MVN_E_NULL;
     hipStream_t st = (hipStream_t)stream;
     if (S == 16 && !unfused_forced()) {  // fused single-kernel path: no scratch, 8 B/symbol of HBM traffic
-        const unsigned grid = (unsigned)((B + kFusedWaves - 1) / kFusedWaves);
-        if (logits_out)
-            hipLaunchKernelGGL((vnet16_fused_kernel<true>), dim3(grid), dim3(64 * kFusedWaves), 0, st, y, y_ld, W1,
-                               b1, W2, b2, W3, b3, dec, dec_ld, logits_out, final_metric, B, T);
-        else
-            hipLaunchKernelGGL((vnet16_fused_kernel<false>), dim3(grid), dim3(64 * kFusedWaves), 0, st, y, y_ld, W1,
-                               b1, W2, b2, W3, b3, dec, dec_ld, logits_out, final_metric, B, T);
+        const bool ldsw = fused_lds_weights();
+        const int wpb = ldsw ? kFusedWavesLds : kFusedWaves;
+        const unsigned grid = (unsigned)((B + wpb - 1) / wpb);
+        const unsigned dyn_lds = ldsw ? fused_dynamic_lds_pad(B) : 0;
+#define MVN_FUSED_LAUNCH(WL, LW)                                                                                       \
+    hipLaunchKernelGGL((vnet16_fused_kernel<WL, LW>), dim3(grid), dim3(64 * wpb), dyn_lds, st, y, y_ld, W1, b1, W2, b2, \
+                       W3, b3, dec, dec_ld, logits_out, final_metric, B, T)
+        if (logits_out) {
+            if (ldsw) MVN_FUSED_LAUNCH(true, true); else MVN_FUSED_LAUNCH(true, false);
+        } else {
+            if (ldsw) MVN_FUSED_LAUNCH(false, true); else MVN_FUSED_LAUNCH(false, false);
+        }
+#undef MVN_FUSED_LAUNCH
         return (int)hipGetLastError();
     }
     const size_t per_block = (size_t)T * (size_t)S * sizeof(float);

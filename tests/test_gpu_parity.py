@@ -219,8 +219,9 @@ def test_vnet16_fused_and_unfused_paths(oracle, dev, monkeypatch, B, T):
     rdec, rlg, rfm = oracle.vnet_decode(y, w, want_logits=True, want_final=True)
     lib = mvn._lib.load()
     ws = torch.empty(B * T * S * 4, dtype=torch.uint8, device=dev)
-    for unfused in ("0", "1"):
+    for unfused, ldsw in (("0", "0"), ("0", "1"), ("1", "0")):
         monkeypatch.setenv("MVN_UNFUSED", unfused)
+        monkeypatch.setenv("MVN_FUSED_LDSW", ldsw)  # register- vs LDS-resident weights in the fused kernel
         for want_logits in (False, True):
             dec = torch.zeros_like(yt)
             fm = torch.empty(B, S, device=dev)
