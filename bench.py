@@ -101,11 +101,27 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    local_dev = local_rank % max(ndev, 1)  # (ranks > devices only happens in the gloo rehearsal below)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    # MVN_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks;
+    # the real run uses nccl (= RCCL over xGMI).
+    backend = os.environ.get("MVN_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def all_reduce(t, op=dist.ReduceOp.SUM):
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+        else:  # gloo: stage through the host
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
 
     B = args.blocks
     weights = golden_weights(dev)
@@ -131,7 +147,7 @@ def main():
     for _ in range(args.steps):
         step()
     if world > 1:
-        dist.all_reduce(counters)  # the single collective: int64[4] error counters over RCCL/xGMI
+        all_reduce(counters)  # the single collective: int64[4] error counters over RCCL/xGMI
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -139,7 +155,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
     total_symbols = float(world) * B * T * args.steps
