@@ -175,6 +175,8 @@ def main():
         ms_acs = event_time_ms(lambda: lib.mvn_acs_sweep_f32(mvn._lib.ptr(cost), mvn._lib.ptr(dec), T, None, B, T, S, st),
                                5, dev)
         ms_step = event_time_ms(step, 3, dev)
+        cfused = torch.zeros(4, dtype=torch.int64, device=dev)
+        ms_fused_count = event_time_ms(lambda: det.val_count(y, tx, None, cfused), 5, dev)
         del cost
         mlp_tflops = FLOP_PER_SYMBOL * B * T / (ms_fused * 1e-3) / 1e12
         acs_gbps = ACS_BYTES_PER_SYMBOL * B * T / (ms_acs * 1e-3) / 1e9
@@ -211,6 +213,9 @@ def main():
                                    "ms_per_launch": ms_acs,
                                    "bytes_per_symbol": ACS_BYTES_PER_SYMBOL},
             "ms_per_step_events": ms_step,
+            "fused_decode_count": {"what": "mvn_vnet_decode_count_f32: decode + error counting in one launch, no decision "
+                                           "store (4 B/symbol of HBM traffic); same counters as `value`'s two-launch step",
+                                   "ms_per_step": ms_fused_count, "symbols_per_s": B * T / (ms_fused_count * 1e-3)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline([w.cpu().numpy() for w in weights], 3450002)

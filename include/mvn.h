@@ -105,6 +105,22 @@ int mvn_vnet_decode_f32(const float *y, int64_t y_ld, const float *W1, const flo
                         mvn_stream_t stream);
 
 /*
+ * One Monte-Carlo step of Trainer.single_eval_at_point (python_code/trainers/trainer.py:232-239) in ONE
+ * launch, 16 states only: VNETDetector.forward(y,'val') with calculate_error_rates folded into the kernel
+ * epilogue, so decisions never travel through HBM (4 B/symbol read, nothing written).
+ *   tx [B, tx_ld>=K] fp32 {0,1}: transmitted words; the first K <= T columns are compared;
+ *   row_mask: uint8[B] or NULL; rows with mask 0 (pilots, trainer.py:100-102) are decoded but not counted;
+ *   counters: device int64[4], += {bit_errors, bits, frame_errors, frames};
+ *   dec: optional [B, dec_ld>=T] decisions output (NULL = do not store).
+ * Returns MVN_E_STATES for S != 16 (use mvn_vnet_decode_f32 + mvn_count_errors there).
+ */
+int mvn_vnet_decode_count_f32(const float *y, int64_t y_ld, const float *W1, const float *b1,
+                              const float *W2, const float *b2, const float *W3, const float *b3,
+                              const float *tx, int64_t tx_ld, int32_t K, const uint8_t *row_mask,
+                              int64_t *counters, float *dec, int64_t dec_ld, int64_t B, int32_t T,
+                              int32_t S, mvn_stream_t stream);
+
+/*
  * calculate_error_rates, python_code/utils/metrics.py:7-17, as integer counters so that
  * 1/2/4/8-GPU results are identical: counters[0..3] += {bit_errors, bits, frame_errors, frames}
  * over rows `rows[i]` (int64 device array, or NULL = rows 0..n_rows-1) and the first K columns.

@@ -28,6 +28,8 @@ SIGNATURES = {
     "mvn_vnet_workspace_bytes": (ctypes.c_size_t, [_i64, _i32, _i32]),
     "mvn_vnet_decode_f32": (ctypes.c_int, [_vp, _i64] + [_vp] * 6 + [_vp, _i64, _vp, _vp, _vp, ctypes.c_size_t,
                                                                    _i64, _i32, _i32, _vp]),
+    "mvn_vnet_decode_count_f32": (ctypes.c_int, [_vp, _i64] + [_vp] * 6 + [_vp, _i64, _i32, _vp, _vp, _vp, _i64,
+                                                 _i64, _i32, _i32, _vp]),
     "mvn_count_errors": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp]),
 }
 

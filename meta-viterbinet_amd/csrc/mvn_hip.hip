@@ -443,33 +443,53 @@ bool fused_lds_weights() {
 }
 
 // Residency choice for the LDS-weights fused kernel.  One wave owns one block for all T symbols, so the
-// kernel's makespan is ceil(B / resident_waves) wave lifetimes: pick the workgroups/CU (3..5, i.e. 12..20
-// waves/CU) whose slot count divides B best, and enforce it by padding the launch's dynamic LDS.
+// kernel's makespan is ceil(B / resident_waves) wave lifetimes: pick the workgroups/CU (3 or 4, i.e. 12 or 16
+// waves/CU; 4 is the VGPR limit) whose slot count divides B best, and enforce it by padding the launch's dynamic LDS.
 // MVN_FUSED_WGS_PER_CU=n overrides.
 unsigned fused_dynamic_lds_pad(int64_t B) {
     constexpr int kStaticLds = 29728;      // ldsA2 + ldsWB + ldsB3w (see -Rpass-analysis)
     constexpr int kLdsPerCu = 160 * 1024;  // gfx950
-    int best = 5;
+    int best = 4;
     const char *e = getenv("MVN_FUSED_WGS_PER_CU");
-    if (e && e[0] >= '1' && e[0] <= '5') {
+    if (e && e[0] >= '1' && e[0] <= '4') {
         best = e[0] - '0';
     } else {
         double best_score = 0.0;
-        for (int w = 3; w <= 5; ++w) {
+        for (int w = 3; w <= 4; ++w) {
             const double slots = 256.0 * w * kFusedWavesLds;
             const double rounds = (double)B / slots;
             const double eff = rounds / (double)(int64_t)(rounds + 0.999999);
-            const double rate = w == 3 ? 0.93 : w == 4 ? 0.98 : 1.0;  // measured relative SIMD throughput
+            const double rate = w == 3 ? 0.89 : 1.0;  // measured relative SIMD throughput (tools/ab_fused.py)
             if (eff * rate > best_score) {
                 best_score = eff * rate;
                 best = w;
             }
         }
     }
-    if (best >= 5) return 0;
+    if (best >= 4) return 0;
     const int per_wg = kLdsPerCu / best;        // at most `best` workgroups fit
     const int need = per_wg - kStaticLds - 512;  // keep (best+1) from fitting
     return need > 0 ? (unsigned)need : 0;
+}
+
+int launch_vnet16_fused(const float *y, int64_t y_ld, const float *W1, const float *b1, const float *W2, const float *b2,
+                        const float *W3, const float *b3, float *dec, int64_t dec_ld, float *logits_out,
+                        float *final_metric, int64_t B, int T, const float *tx, int64_t tx_ld, int K,
+                        const unsigned char *row_mask, unsigned long long *counters, hipStream_t st) {
+    const bool ldsw = fused_lds_weights();
+    const int wpb = ldsw ? kFusedWavesLds : kFusedWaves;
+    const unsigned grid = (unsigned)((B + wpb - 1) / wpb);
+    const unsigned dyn_lds = ldsw ? fused_dynamic_lds_pad(B) : 0;
+#define MVN_FUSED_LAUNCH(WL, LW)                                                                                       \
+    hipLaunchKernelGGL((vnet16_fused_kernel<WL, LW>), dim3(grid), dim3(64 * wpb), dyn_lds, st, y, y_ld, W1, b1, W2, b2, \
+                       W3, b3, dec, dec_ld, logits_out, final_metric, B, T, tx, tx_ld, K, row_mask, counters)
+    if (logits_out) {
+        if (ldsw) MVN_FUSED_LAUNCH(true, true); else MVN_FUSED_LAUNCH(true, false);
+    } else {
+        if (ldsw) MVN_FUSED_LAUNCH(false, true); else MVN_FUSED_LAUNCH(false, false);
+    }
+#undef MVN_FUSED_LAUNCH
+    return (int)hipGetLastError();
 }
 
 // MVN_GENERIC_SWEEP=1 forces the generic state-per-lane LDS sweep at S=16 (testing).
@@ -590,22 +610,9 @@ int mvn_vnet_decode_f32(const float *y, int64_t y_ld, const float *W1, const flo
     if (B == 0 || T == 0) return MVN_OK;
     if (!y || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !dec) return MVN_E_NULL;
     hipStream_t st = (hipStream_t)stream;
-    if (S == 16 && !unfused_forced()) {  // fused single-kernel path: no scratch, 8 B/symbol of HBM traffic
-        const bool ldsw = fused_lds_weights();
-        const int wpb = ldsw ? kFusedWavesLds : kFusedWaves;
-        const unsigned grid = (unsigned)((B + wpb - 1) / wpb);
-        const unsigned dyn_lds = ldsw ? fused_dynamic_lds_pad(B) : 0;
-#define MVN_FUSED_LAUNCH(WL, LW)                                                                                       \
-    hipLaunchKernelGGL((vnet16_fused_kernel<WL, LW>), dim3(grid), dim3(64 * wpb), dyn_lds, st, y, y_ld, W1, b1, W2, b2, \
-                       W3, b3, dec, dec_ld, logits_out, final_metric, B, T)
-        if (logits_out) {
-            if (ldsw) MVN_FUSED_LAUNCH(true, true); else MVN_FUSED_LAUNCH(true, false);
-        } else {
-            if (ldsw) MVN_FUSED_LAUNCH(false, true); else MVN_FUSED_LAUNCH(false, false);
-        }
-#undef MVN_FUSED_LAUNCH
-        return (int)hipGetLastError();
-    }
+    if (S == 16 && !unfused_forced())  // fused single-kernel path: no scratch, 8 B/symbol of HBM traffic
+        return launch_vnet16_fused(y, y_ld, W1, b1, W2, b2, W3, b3, dec, dec_ld, logits_out, final_metric, B, T, nullptr, 0,
+                                   0, nullptr, nullptr, st);
     const size_t per_block = (size_t)T * (size_t)S * sizeof(float);
     int64_t slice = B;
     float *buf = logits_out;
@@ -626,6 +633,19 @@ int mvn_vnet_decode_f32(const float *y, int64_t y_ld, const float *W1, const flo
         if (rc) return rc;
     }
     return MVN_OK;
+}
+
+int mvn_vnet_decode_count_f32(const float *y, int64_t y_ld, const float *W1, const float *b1, const float *W2,
+                              const float *b2, const float *W3, const float *b3, const float *tx, int64_t tx_ld,
+                              int32_t K, const uint8_t *row_mask, int64_t *counters, float *dec, int64_t dec_ld,
+                              int64_t B, int32_t T, int32_t S, mvn_stream_t stream) {
+    if (B < 0 || T < 0 || K < 0 || K > T || y_ld < T || tx_ld < K || (dec && dec_ld < T)) return MVN_E_DIMS;
+    if (S != 16) return MVN_E_STATES;  // fused epilogue exists for the 16-state kernel only
+    if (!counters) return MVN_E_NULL;
+    if (B == 0 || T == 0) return MVN_OK;
+    if (!y || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !tx) return MVN_E_NULL;
+    return launch_vnet16_fused(y, y_ld, W1, b1, W2, b2, W3, b3, dec, dec_ld, nullptr, nullptr, B, T, tx, tx_ld, K,
+                               row_mask, (unsigned long long *)counters, (hipStream_t)stream);
 }
 
 int mvn_count_errors(const float *dec, int64_t dec_ld, const float *tx, int64_t tx_ld, const int64_t *rows,

@@ -137,6 +137,33 @@ def _vnet_val(y: torch.Tensor, params, n_states: int, T: int, return_logits: boo
     return (decoded_word, logits) if return_logits else decoded_word
 
 
+def _vnet_val_count(y, params, n_states, T, tx, rows=None, counters=None, return_decisions=False):
+    """One Monte-Carlo step in one launch (mvn_vnet_decode_count_f32, 16 states): decode + on-device error
+    counting over the first tx.shape[1] columns of the rows in `rows` (None = all).  Decisions are only stored
+    when asked for.  Returns the int64[4] counters tensor (and the decisions)."""
+    _lib.require_gpu_tensor(y, "y")
+    yc = _as_f32(y)
+    B, Ty = yc.shape
+    _check_T(T, yc)
+    w = [_as_f32(p).to(yc.device) for p in params]
+    txc = _as_f32(tx).to(yc.device)
+    if txc.shape[0] != B or txc.shape[1] > T:
+        raise ValueError("tx must be [B, K<=T]")
+    if counters is None:
+        counters = torch.zeros(4, dtype=torch.int64, device=yc.device)
+    mask = None
+    if rows is not None:
+        mask = torch.zeros(B, dtype=torch.uint8, device=yc.device)
+        mask[rows.to(yc.device)] = 1
+    dec = torch.zeros(yc.shape, dtype=torch.float32, device=yc.device) if return_decisions else None
+    with torch.cuda.device(yc.device):
+        rc = _lib.load().mvn_vnet_decode_count_f32(_lib.ptr(yc), Ty, *[_lib.ptr(t) for t in w], _lib.ptr(txc),
+                                                   txc.stride(0), txc.shape[1], _lib.ptr(mask), _lib.ptr(counters),
+                                                   _lib.ptr(dec), Ty, B, T, n_states, _lib.current_stream(yc.device))
+    _lib.check(rc, "mvn_vnet_decode_count_f32")
+    return (counters, dec) if return_decisions else counters
+
+
 class VNETDetector(nn.Module):
     """ViterbiNet: the VA sweep with branch metrics from a per-symbol MLP (vnet_detector.py:11-63).
     Parameter names net.{0,2,4}.{weight,bias} match the reference so checkpoints interchange."""
@@ -160,6 +187,11 @@ class VNETDetector(nn.Module):
         if phase == "val":
             return _vnet_val(y, list(self.net.parameters()), self.n_states, self.transmission_lengths["val"])
         return self.net(y.reshape(-1, 1)).reshape(y.shape[0], y.shape[1], self.n_states)
+
+    def val_count(self, y, tx, rows=None, counters=None, return_decisions=False):
+        """forward(y,'val') + calculate_error_rates fused in one launch (16 states); see _vnet_val_count."""
+        return _vnet_val_count(y, list(self.net.parameters()), self.n_states, self.transmission_lengths["val"], tx, rows,
+                               counters, return_decisions)
 
     @torch.no_grad()
     def logits(self, y: torch.Tensor) -> torch.Tensor:

@@ -58,8 +58,11 @@ def eval_counters(detector: Callable, tx: torch.Tensor, rx: torch.Tensor, snr: f
     """One Monte-Carlo point on THIS rank's rows: detect -> count -> (optionally) all-reduce.
     `tx`/`rx` are the rank-local shards; `rows` are local row indices counted (None = all).
     Returns int64[4] counters (global sums when reduce=True and a process group is up)."""
-    detected = detector(rx, "val", snr, gamma)
-    counters = counter(detected[:, : tx.shape[1]], tx, rows)
+    if counter is _gpu_counter and getattr(detector, "n_states", None) == 16 and hasattr(detector, "val_count"):
+        counters = detector.val_count(rx, tx, rows)  # decode + count in one launch, decisions never stored
+    else:
+        detected = detector(rx, "val", snr, gamma)
+        counters = counter(detected[:, : tx.shape[1]], tx, rows)
     if reduce and dist.is_available() and dist.is_initialized():
         dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=group)
     return counters

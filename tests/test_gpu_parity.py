@@ -299,6 +299,33 @@ def test_count_errors_vs_oracle(oracle, dev):
         assert got_all.tolist() == oracle.count_errors(dec[:, :K], tx).tolist()
 
 
+@pytest.mark.parametrize("B,T,K", [(1, 1, 1), (7, 45, 45), (300, 136, 120), (1000, 257, 257)])
+def test_fused_decode_count(oracle, dev, B, T, K):
+    """mvn_vnet_decode_count_f32: counters equal oracle decode + oracle count; optional decisions equal too;
+    pilots (rows outside `rows`) are decoded but not counted."""
+    S = 16
+    rng = np.random.RandomState(B + T)
+    w = _rand_weights(S, rng)
+    y = rng.normal(0, 1.5, (B, T)).astype(np.float32)
+    tx = rng.randint(0, 2, (B, K)).astype(np.float32)
+    rdec = oracle.vnet_decode(y, w)
+    det = _vnet_with(w, S, T, dev)
+    yt, tt = torch.tensor(y, device=dev), torch.tensor(tx, device=dev)
+    c, dec = det.val_count(yt, tt, return_decisions=True)
+    assert c.tolist() == oracle.count_errors(rdec[:, :K], tx).tolist()
+    assert np.array_equal(_np(dec), rdec)
+    rows = np.array([i for i in range(B) if i % 5 != 0] or [0], np.int64)
+    c2 = det.val_count(yt, tt, rows=torch.tensor(rows, device=dev))
+    assert c2.tolist() == oracle.count_errors(rdec[:, :K], tx, rows).tolist()
+    # accumulation into a caller-provided counter tensor
+    c3 = det.val_count(yt, tt, counters=c2.clone())
+    assert c3.tolist() == (np.array(c2.tolist()) + np.array(c.tolist())).tolist()
+    # the harness takes the fused route and agrees with the two-launch route
+    ser, fer, c4 = mvn.single_eval_at_point(det, tt, yt, 10, 0.2, torch.tensor(rows, device=dev))
+    assert c4.tolist() == c2.tolist()
+    assert mvn.count_errors(det(yt, "val")[:, :K], tt, torch.tensor(rows, device=dev)).tolist() == c2.tolist()
+
+
 def test_detector_api_contract(dev):
     """Shapes/dtypes/exceptions a trainer relies on."""
     det = mvn.VNETDetector(16, {"train": 20, "val": 20}).to(dev)
