@@ -130,6 +130,21 @@ int mvn_count_errors(const float *dec, int64_t dec_ld, const float *tx, int64_t 
                      const int64_t *rows, int64_t n_rows, int32_t K, int64_t *counters,
                      mvn_stream_t stream);
 
+/*
+ * Reed-Solomon outer code, batched over words; bits are fp32 {0,1}, 8 per GF(2^8)
+ * symbol, MSB first (np.packbits).  Same code and same behaviour past the correction capacity as
+ * python_code/ecc/rs_main.py: encode (:9-18) / decode (:21-37) -- prim 0x11d, generator 2, nsym parity bytes,
+ * nbits/8 <= 255, nsym <= 64.
+ *   decode: rx_bits [B, ld_in >= nbits] -> msg_bits [B, ld_out >= nbits - 8*nsym];
+ *           status: int32[B] or NULL: 0 decoded, 1 = more errors than nsym/2 detected (uncorrected systematic
+ *           part returned, rs_main.py:31-33), 2 = the reference would raise (never observed);
+ *   encode: msg_bits [B, ld_in >= kbits] -> cw_bits [B, ld_out >= kbits + 8*nsym].
+ */
+int mvn_rs_decode_bits_f32(const float *rx_bits, int64_t ld_in, float *msg_bits, int64_t ld_out,
+                           int32_t *status, int64_t B, int32_t nbits, int32_t nsym, mvn_stream_t stream);
+int mvn_rs_encode_bits_f32(const float *msg_bits, int64_t ld_in, float *cw_bits, int64_t ld_out, int64_t B,
+                           int32_t kbits, int32_t nsym, mvn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -371,6 +371,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 
 #include "vnet16_fused.inc"
 #include "sweep16_rows.inc"
+#include "rs_codec.inc"
 
 // -------------------------------------------------------------------------------------------
 // metrics.py:7-17 as integer counters.  One wave per row, block-level reduction, one atomic
@@ -646,6 +647,46 @@ int mvn_vnet_decode_count_f32(const float *y, int64_t y_ld, const float *W1, con
     if (!y || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !tx) return MVN_E_NULL;
     return launch_vnet16_fused(y, y_ld, W1, b1, W2, b2, W3, b3, dec, dec_ld, nullptr, nullptr, B, T, tx, tx_ld, K,
                                row_mask, (unsigned long long *)counters, (hipStream_t)stream);
+}
+
+int mvn_rs_decode_bits_f32(const float *rx_bits, int64_t ld_in, float *msg_bits, int64_t ld_out, int32_t *status,
+                           int64_t B, int32_t nbits, int32_t nsym, mvn_stream_t stream) {
+    if (B < 0 || nbits < 0 || (nbits % 8) != 0 || nsym < 1 || nsym > 64) return MVN_E_DIMS;
+    const int n = nbits / 8;
+    if (n <= nsym || n > 255 || ld_in < nbits || ld_out < nbits - 8 * nsym) return MVN_E_DIMS;
+    if (B == 0) return MVN_OK;
+    if (!rx_bits || !msg_bits) return MVN_E_NULL;
+    const unsigned grid = (unsigned)((B + kRsThreads - 1) / kRsThreads);
+    hipStream_t st = (hipStream_t)stream;
+#define MVN_RS_DEC(NS) \
+    hipLaunchKernelGGL((rs_decode_kernel<NS>), dim3(grid), dim3(kRsThreads), 0, st, rx_bits, ld_in, msg_bits, ld_out, status, B, n, nsym)
+    if (nsym <= 2) MVN_RS_DEC(2);
+    else if (nsym <= 8) MVN_RS_DEC(8);
+    else if (nsym <= 16) MVN_RS_DEC(16);
+    else if (nsym <= 32) MVN_RS_DEC(32);
+    else MVN_RS_DEC(64);
+#undef MVN_RS_DEC
+    return (int)hipGetLastError();
+}
+
+int mvn_rs_encode_bits_f32(const float *msg_bits, int64_t ld_in, float *cw_bits, int64_t ld_out, int64_t B,
+                           int32_t kbits, int32_t nsym, mvn_stream_t stream) {
+    if (B < 0 || kbits < 8 || (kbits % 8) != 0 || nsym < 1 || nsym > 64) return MVN_E_DIMS;
+    const int k = kbits / 8;
+    if (k + nsym > 255 || ld_in < kbits || ld_out < kbits + 8 * nsym) return MVN_E_DIMS;
+    if (B == 0) return MVN_OK;
+    if (!msg_bits || !cw_bits) return MVN_E_NULL;
+    const unsigned grid = (unsigned)((B + kRsThreads - 1) / kRsThreads);
+    hipStream_t st = (hipStream_t)stream;
+#define MVN_RS_ENC(NS) \
+    hipLaunchKernelGGL((rs_encode_kernel<NS>), dim3(grid), dim3(kRsThreads), 0, st, msg_bits, ld_in, cw_bits, ld_out, B, k, nsym)
+    if (nsym <= 2) MVN_RS_ENC(2);
+    else if (nsym <= 8) MVN_RS_ENC(8);
+    else if (nsym <= 16) MVN_RS_ENC(16);
+    else if (nsym <= 32) MVN_RS_ENC(32);
+    else MVN_RS_ENC(64);
+#undef MVN_RS_ENC
+    return (int)hipGetLastError();
 }
 
 int mvn_count_errors(const float *dec, int64_t dec_ld, const float *tx, int64_t tx_ld, const int64_t *rows,

@@ -339,3 +339,209 @@ int mvn_oracle_calculate_states(const float *words, int64_t B, int T, int L, int
         }
     return 0;
 }
+
+/* =====================================================================================================
+ * Reed-Solomon outer code over GF(2^8) (SURVEY 8f "next #2"): restatement of python_code/ecc/
+ * (rs_main.py:9-37, rs_encoder.py:7-37, rs_decoder.py:37-218, polynomials_manipulation.py:85-125), the
+ * "Reed-Solomon codes for coders" codec: prim 0x11d, generator 2, fcr 0, systematic, nsym parity bytes,
+ * Berlekamp-Massey + brute-force root search + Forney.  Polynomials follow the reference's list
+ * conventions (highest degree first unless noted).  Bits are packed MSB-first (np.packbits).
+ * Pinned by tests/golden/g8_rs.npz.
+ * ===================================================================================================== */
+#define RS_MAX_N 255
+#define RS_MAX_NSYM 64
+static uint8_t rs_exp[512];
+static uint8_t rs_log[256];
+static int rs_ready = 0;
+
+static void rs_init_tables(void) { /* polynomials_manipulation.py:85-110 */
+    if (rs_ready) return;
+    int x = 1;
+    for (int i = 0; i < 255; ++i) {
+        rs_exp[i] = (uint8_t)x;
+        rs_log[x] = (uint8_t)i;
+        x <<= 1;
+        if (x & 0x100) x ^= 0x11d;
+    }
+    for (int i = 255; i < 512; ++i) rs_exp[i] = rs_exp[i - 255];
+    rs_ready = 1;
+}
+static inline int rs_mul(int x, int y) { return (x == 0 || y == 0) ? 0 : rs_exp[rs_log[x] + rs_log[y]]; }
+static inline int rs_inv(int x) { return rs_exp[255 - rs_log[x]]; }
+static inline int rs_pow2(int power) { /* gf_pow(2, power), python % semantics */
+    int e = power % 255;
+    if (e < 0) e += 255;
+    return rs_exp[e];
+}
+static inline int rs_div(int x, int y) { return x == 0 ? 0 : rs_exp[(rs_log[x] + 255 - rs_log[y]) % 255]; }
+/* gf_poly_eval: Horner, highest degree first */
+static int rs_poly_eval(const int *p, int len, int x) {
+    int y = p[0];
+    for (int i = 1; i < len; ++i) y = rs_mul(y, x) ^ p[i];
+    return y;
+}
+/* gf_poly_mul: r has len p + len q - 1 */
+static void rs_poly_mul(const int *p, int lp, const int *q, int lq, int *r) {
+    for (int i = 0; i < lp + lq - 1; ++i) r[i] = 0;
+    for (int j = 0; j < lq; ++j)
+        for (int i = 0; i < lp; ++i) r[i + j] ^= rs_mul(p[i], q[j]);
+}
+
+/* rs_encoder.py:7-37 on bytes: msg[k] -> out[k+nsym] */
+int mvn_oracle_rs_encode_bytes(const uint8_t *msg, int k, int nsym, uint8_t *out) {
+    rs_init_tables();
+    if (k < 1 || nsym < 1 || nsym > RS_MAX_NSYM || k + nsym > RS_MAX_N) return -1;
+    int gen[RS_MAX_NSYM + 1], tmp[RS_MAX_NSYM + 2], glen = 1;
+    gen[0] = 1;
+    for (int i = 0; i < nsym; ++i) { /* rs_generator_poly */
+        int f[2] = {1, rs_pow2(i)};
+        rs_poly_mul(gen, glen, f, 2, tmp);
+        glen += 1;
+        memcpy(gen, tmp, sizeof(int) * (size_t)glen);
+    }
+    int buf[RS_MAX_N];
+    for (int i = 0; i < k; ++i) buf[i] = msg[i];
+    for (int i = k; i < k + nsym; ++i) buf[i] = 0;
+    for (int i = 0; i < k; ++i) {
+        int coef = buf[i];
+        if (coef != 0)
+            for (int j = 1; j < glen; ++j) buf[i + j] ^= rs_mul(gen[j], coef);
+    }
+    for (int i = 0; i < k; ++i) out[i] = msg[i];
+    for (int i = k; i < k + nsym; ++i) out[i] = (uint8_t)buf[i];
+    return 0;
+}
+
+/* rs_main.py:21-37 on bytes: rx[n] -> out[n-nsym]; returns 0 ok, 1 = "too many errors" branch (:31-33),
+ * 2 = the reference would raise ValueError("Could not find error magnitude") (rs_decoder.py:123). */
+int mvn_oracle_rs_decode_bytes(const uint8_t *rx, int n, int nsym, uint8_t *out) {
+    rs_init_tables();
+    if (nsym < 1 || nsym > RS_MAX_NSYM || n <= nsym || n > RS_MAX_N) return -1;
+    const int k = n - nsym;
+    int msg[RS_MAX_N];
+    for (int i = 0; i < n; ++i) msg[i] = rx[i];
+    /* rs_calc_syndromes (:37-47): synd = [0] + [eval(msg, 2^i)] */
+    int synd[RS_MAX_NSYM + 1];
+    synd[0] = 0;
+    for (int i = 0; i < nsym; ++i) synd[i + 1] = rs_poly_eval(msg, n, rs_pow2(i));
+    /* rs_find_error_locator (:140-205), no erasures; synd_shift = 1 */
+    int err_loc[RS_MAX_NSYM + 2], old_loc[RS_MAX_NSYM + 3], new_loc[RS_MAX_NSYM + 3];
+    int el = 1, ol = 1;
+    err_loc[0] = 1;
+    old_loc[0] = 1;
+    for (int i = 0; i < nsym; ++i) {
+        const int K = i + 1;
+        int delta = synd[K];
+        for (int j = 1; j < el; ++j) delta ^= rs_mul(err_loc[el - (j + 1)], synd[K - j]);
+        old_loc[ol++] = 0; /* old_loc + [0] */
+        if (delta != 0) {
+            if (ol > el) {
+                for (int t = 0; t < ol; ++t) new_loc[t] = rs_mul(old_loc[t], delta);
+                const int inv = rs_inv(delta);
+                for (int t = 0; t < el; ++t) old_loc[t] = rs_mul(err_loc[t], inv);
+                const int nl = ol;
+                ol = el;
+                el = nl;
+                memcpy(err_loc, new_loc, sizeof(int) * (size_t)el);
+            }
+            /* err_loc = gf_poly_add(err_loc, gf_poly_scale(old_loc, delta)): right-aligned xor */
+            int rl = el > ol ? el : ol, r[RS_MAX_NSYM + 3];
+            for (int t = 0; t < rl; ++t) r[t] = 0;
+            for (int t = 0; t < el; ++t) r[t + rl - el] = err_loc[t];
+            for (int t = 0; t < ol; ++t) r[t + rl - ol] ^= rs_mul(old_loc[t], delta);
+            el = rl;
+            memcpy(err_loc, r, sizeof(int) * (size_t)el);
+        }
+    }
+    int lead = 0;
+    while (lead < el && err_loc[lead] == 0) ++lead; /* drop leading zeros */
+    const int errs = el - lead - 1;
+    if (errs * 2 > nsym) { /* err_loc is None -> uncorrected systematic part */
+        for (int i = 0; i < k; ++i) out[i] = rx[i];
+        return 1;
+    }
+    /* rs_find_errors(err_loc[::-1], n) (:207-218) */
+    int rev[RS_MAX_NSYM + 2], rl = el - lead;
+    for (int t = 0; t < rl; ++t) rev[t] = err_loc[el - 1 - t];
+    int pos[RS_MAX_N], npos = 0;
+    for (int i = 0; i < n; ++i)
+        if (rs_poly_eval(rev, rl, rs_pow2(i)) == 0) pos[npos++] = n - 1 - i;
+    /* rs_correct_errata (:83-137) */
+    int coef_pos[RS_MAX_N], loc[RS_MAX_N + 1], ll = 1, tmp[RS_MAX_N + 2];
+    loc[0] = 1;
+    for (int i = 0; i < npos; ++i) {
+        coef_pos[i] = n - 1 - pos[i];
+        int f[2] = {rs_pow2(coef_pos[i]), 1}; /* gf_poly_add([1],[a,0]) = [a,1] */
+        rs_poly_mul(loc, ll, f, 2, tmp);
+        ll += 1;
+        memcpy(loc, tmp, sizeof(int) * (size_t)ll);
+    }
+    /* err_eval = (synd[::-1] * loc) mod x^(ll): the last ll coefficients; then reversed */
+    int srev[RS_MAX_NSYM + 1], prod[RS_MAX_NSYM + RS_MAX_N + 2];
+    for (int t = 0; t <= nsym; ++t) srev[t] = synd[nsym - t];
+    rs_poly_mul(srev, nsym + 1, loc, ll, prod);
+    const int pl = nsym + 1 + ll - 1;
+    /* gf_poly_div by [1,0,...,0] (length ll+1): remainder = last ll coefficients (needs pl >= ll) */
+    int ev[RS_MAX_N + 1]; /* err_eval[::-1] of the reference == remainder as is (highest degree first) */
+    for (int t = 0; t < ll; ++t) ev[t] = prod[pl - ll + t];
+    int X[RS_MAX_N];
+    for (int i = 0; i < npos; ++i) X[i] = rs_pow2(-(255 - coef_pos[i]));
+    int E[RS_MAX_N];
+    for (int i = 0; i < n; ++i) E[i] = 0;
+    for (int i = 0; i < npos; ++i) {
+        const int Xi_inv = rs_inv(X[i]);
+        int prime = 1;
+        for (int j = 0; j < npos; ++j)
+            if (j != i) prime = rs_mul(prime, 1 ^ rs_mul(Xi_inv, X[j]));
+        int yv = rs_poly_eval(ev, ll, Xi_inv); /* gf_poly_eval(err_eval[::-1], Xi_inv) with err_eval = remainder[::-1] */
+        yv = rs_mul(X[i], yv);
+        if (prime == 0) {
+            for (int t = 0; t < k; ++t) out[t] = rx[t];
+            return 2;
+        }
+        E[pos[i]] = rs_div(yv, prime);
+    }
+    for (int i = 0; i < k; ++i) out[i] = (uint8_t)(msg[i] ^ E[i]);
+    return 0;
+}
+
+/* bit-level wrappers (rs_main.py:9-37): fp32 {0,1} words, MSB-first packing */
+int mvn_oracle_rs_encode_bits(const float *bits, int64_t ld_in, float *out, int64_t ld_out, int64_t B,
+                              int kbits, int nsym) {
+    if (kbits % 8) return -1;
+    const int k = kbits / 8;
+    for (int64_t b = 0; b < B; ++b) {
+        uint8_t msg[RS_MAX_N], cw[RS_MAX_N];
+        for (int i = 0; i < k; ++i) {
+            int v = 0;
+            for (int j = 0; j < 8; ++j) v = (v << 1) | ((int)bits[b * ld_in + 8 * i + j] & 1);
+            msg[i] = (uint8_t)v;
+        }
+        int rc = mvn_oracle_rs_encode_bytes(msg, k, nsym, cw);
+        if (rc) return rc;
+        for (int i = 0; i < k + nsym; ++i)
+            for (int j = 0; j < 8; ++j) out[b * ld_out + 8 * i + j] = (float)((cw[i] >> (7 - j)) & 1);
+    }
+    return 0;
+}
+
+int mvn_oracle_rs_decode_bits(const float *bits, int64_t ld_in, float *out, int64_t ld_out, int64_t B,
+                              int nbits, int nsym, int32_t *status) {
+    if (nbits % 8) return -1;
+    const int n = nbits / 8;
+    rs_init_tables();
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; ++b) {
+        uint8_t rx[RS_MAX_N], msg[RS_MAX_N];
+        for (int i = 0; i < n; ++i) {
+            int v = 0;
+            for (int j = 0; j < 8; ++j) v = (v << 1) | ((int)bits[b * ld_in + 8 * i + j] & 1);
+            rx[i] = (uint8_t)v;
+        }
+        int rc = mvn_oracle_rs_decode_bytes(rx, n, nsym, msg);
+        if (status) status[b] = rc;
+        for (int i = 0; i < n - nsym; ++i)
+            for (int j = 0; j < 8; ++j) out[b * ld_out + 8 * i + j] = (float)((msg[i] >> (7 - j)) & 1);
+    }
+    return 0;
+}

@@ -192,3 +192,26 @@ def sigmoid(x) -> np.ndarray:
     out = np.empty_like(x)
     lib().mvn_oracle_sigmoid_array(_p(x), _p(out), ctypes.c_int64(x.size))
     return out
+
+
+def rs_encode_bits(bits, nsym: int) -> np.ndarray:
+    """ecc.rs_main.encode, batched: bits [B, K] {0,1} -> codewords [B, K + 8*nsym] (rs_main.py:9-18)."""
+    b = _f32(bits)
+    B, K = b.shape
+    out = np.empty((B, K + 8 * nsym), np.float32)
+    _check(lib().mvn_oracle_rs_encode_bits(_p(b), ctypes.c_int64(K), _p(out), ctypes.c_int64(K + 8 * nsym),
+                                           ctypes.c_int64(B), ctypes.c_int(K), ctypes.c_int(nsym)), "rs_encode_bits")
+    return out
+
+
+def rs_decode_bits(bits, nsym: int, want_status: bool = False):
+    """ecc.rs_main.decode, batched: received bits [B, N] -> message bits [B, N - 8*nsym] (rs_main.py:21-37).
+    status: 0 decoded, 1 'too many errors' (uncorrected systematic part returned), 2 reference would raise."""
+    b = _f32(bits)
+    B, N = b.shape
+    out = np.empty((B, N - 8 * nsym), np.float32)
+    st = np.zeros(B, np.int32)
+    _check(lib().mvn_oracle_rs_decode_bits(_p(b), ctypes.c_int64(N), _p(out), ctypes.c_int64(N - 8 * nsym),
+                                           ctypes.c_int64(B), ctypes.c_int(N), ctypes.c_int(nsym),
+                                           st.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))), "rs_decode_bits")
+    return (out, st) if want_status else out

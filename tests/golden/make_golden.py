@@ -327,11 +327,107 @@ def g7_by_word(trained):
     save("g7_by_word", **out)
 
 
+# ----------------------------------------------------------------------------- G9
+def g9_by_word_va():
+    """eval_by_word (trainer.py:267-354) end to end with the deterministic VA detector and the RS(17,15) outer
+    code: per-block ser, transmitted/received/detected words."""
+    out = {}
+    for coef, fading in (("time_decay", True), ("cost2100", False)):
+        tr = VATrainer(eval_mode="by_word", use_ecc=True, n_symbols=2, memory_length=4, val_block_length=120,
+                       val_frames=12, subframes_in_frame=25, channel_coefficients=coef, fading_in_channel=fading,
+                       fading_in_decoder=fading, fading_taps_type=2, noisy_est_var=0, self_supervised=False,
+                       online_meta=False, val_SNR_start=9, val_SNR_end=9, gamma=0.2, weights_dir=TMP,
+                       noise_seed=3450002, word_seed=7860002)
+        rec = {"y": [], "dec": [], "count": []}
+        orig_forward = tr.detector.forward
+
+        def spy(y, phase, snr=None, gamma=None, count=None, _f=orig_forward):
+            r = _f(y, phase, snr, gamma, count)
+            rec["y"].append(y.detach().numpy().copy())
+            rec["dec"].append(r.detach().numpy().copy())
+            rec["count"].append(-1 if count is None else count)
+            return r
+
+        tr.detector.forward = spy
+        # the trainer draws the words inside eval_by_word; replay the same draw first to capture tx
+        t2 = VATrainer(eval_mode="by_word", use_ecc=True, n_symbols=2, memory_length=4, val_block_length=120,
+                       val_frames=12, subframes_in_frame=25, channel_coefficients=coef, fading_in_channel=fading,
+                       fading_in_decoder=fading, fading_taps_type=2, noisy_est_var=0, self_supervised=False,
+                       online_meta=False, val_SNR_start=9, val_SNR_end=9, gamma=0.2, weights_dir=TMP,
+                       noise_seed=3450002, word_seed=7860002)
+        tx, rx = t2.channel_dataset["val"].__getitem__(snr_list=[9], gamma=0.2)
+        ser_by_word = tr.evaluate()
+        assert np.array_equal(np.concatenate(rec["y"]), rx.numpy())
+        out[f"{coef}_ser_by_word"] = np.asarray(ser_by_word, np.float64)
+        out[f"{coef}_tx"] = tx.numpy().astype(np.uint8)
+        out[f"{coef}_y"] = rx.numpy()
+        out[f"{coef}_detected"] = np.concatenate(rec["dec"]).astype(np.uint8)
+        out[f"{coef}_count"] = np.array(rec["count"], np.int64)
+        out[f"{coef}_data_indices"] = tr.data_indices.numpy()
+        out[f"{coef}_meta"] = np.array([4, 12, 25, 136, 9, int(fading), 2, 2], np.int64)  # L,frames,sub,T,snr,fading,taps,nsym
+        print(coef, "mean ser_by_word", float(np.mean(ser_by_word)))
+    save("g9_by_word_va", **out)
+
+
+# ----------------------------------------------------------------------------- G8
+def g8_rs():
+    """RS(n,k) KATs through the reference's own encode/decode (rs_main.py:9-37), incl. patterns beyond the
+    correction capacity (the reference then returns the uncorrected word or mis-corrects: both are pinned)."""
+    from python_code.ecc.rs_main import encode, decode
+
+    rng = np.random.RandomState(88)
+    out = {}
+    for (kbits, nsym, ncase) in ((120, 2, 160), (120, 8, 160), (480, 8, 60), (8, 2, 24), (1976, 8, 6)):
+        msgs, cws, rxs, decs = [], [], [], []
+        for c in range(ncase):
+            b = rng.randint(0, 2, kbits)
+            cw = encode(b, nsym)
+            rx = cw.copy()
+            mode = c % 8
+            nbytes = len(cw) // 8
+            if mode in (1, 2, 3, 4, 5):  # 1..nsym/2+2 corrupted symbols (random byte values)
+                nerr = min(nbytes, max(1, (mode * (nsym // 2 + 2)) // 5))
+                for pos in rng.choice(nbytes, nerr, replace=False):
+                    flip = rng.randint(1, 256)
+                    bits = np.unpackbits(np.array([flip], np.uint8))
+                    rx[8 * pos: 8 * pos + 8] ^= bits
+            elif mode == 6:  # scattered single-bit errors
+                for pos in rng.choice(len(cw), min(len(cw), nsym), replace=False):
+                    rx[pos] ^= 1
+            elif mode == 7:  # heavy corruption
+                rx = rng.randint(0, 2, len(cw))
+            d = decode(rx, nsym)
+            msgs.append(b)
+            cws.append(cw)
+            rxs.append(rx)
+            decs.append(d)
+        tag = f"k{kbits}_n{nsym}"
+        out[tag + "_msg"] = np.array(msgs, np.uint8)
+        out[tag + "_cw"] = np.array(cws, np.uint8)
+        out[tag + "_rx"] = np.array(rxs, np.uint8)
+        out[tag + "_dec"] = np.array(decs, np.uint8)
+        print(tag, "cases", ncase, "decoded==msg:", int(np.sum(np.all(np.array(decs) == np.array(msgs), axis=1))))
+    save("g8_rs", **out)
+
+
 if __name__ == "__main__":
     import contextlib
     import io
 
     patch_cost2100()
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+        g8_rs()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+        import contextlib
+        import io
+
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            g9_by_word_va()
+        print("\n".join(l for l in buf.getvalue().splitlines() if l.startswith(("time_decay", "cost2100", "wrote"))))
+        sys.exit(0)
+    g8_rs()
     g1_acs()
     g5_kats()
     g6_channels()
@@ -342,6 +438,7 @@ if __name__ == "__main__":
     print("\n".join(l for l in buf.getvalue().splitlines() if l.startswith(("S", "wrote", "best"))))
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
+        g9_by_word_va()
         g7_by_word(trained4)
     print("\n".join(l for l in buf.getvalue().splitlines() if l.startswith(("time_decay", "cost2100", "wrote", "Final"))))
     print("torch", torch.__version__, "numpy", np.__version__)

@@ -382,3 +382,55 @@ def test_config2_vnet_full_size(golden, oracle, dev):
     ser, fer, c = mvn.single_eval_at_point(det, tx, y, 10.0, 0.2)
     assert c.tolist()[1] == B * T and 0 < ser < 0.05  # trained weights: a sane SER at 10 dB
     assert torch.all(dec[:, 0] == 0)  # Q1
+
+
+# ---------------------------------------------------------------- next #2: Reed-Solomon outer code on the GPU
+@pytest.mark.parametrize("tag,nsym", [("k120_n2", 2), ("k120_n8", 8), ("k480_n8", 8), ("k8_n2", 2), ("k1976_n8", 8)])
+def test_rs_codec_golden_gpu(golden, dev, tag, nsym):
+    g = golden("g8_rs")
+    msg, cw, rx, dec = (torch.tensor(g[f"{tag}_{k}"].astype(np.float32), device=dev) for k in ("msg", "cw", "rx", "dec"))
+    assert torch.equal(mvn.rs_encode(msg, nsym), cw)
+    got, st = mvn.rs_decode(rx, nsym, return_status=True)
+    assert torch.equal(got, dec) and not bool((st == 2).any())
+    assert torch.equal(mvn.rs_decode(cw, nsym), msg)
+
+
+@pytest.mark.parametrize("kbits,nsym", [(120, 2), (120, 8), (64, 16), (800, 32), (1024, 64), (8, 1)])
+def test_rs_codec_vs_oracle(oracle, dev, kbits, nsym):
+    rng = np.random.RandomState(kbits + nsym)
+    B = 700
+    msg = rng.randint(0, 2, (B, kbits)).astype(np.float32)
+    cw = oracle.rs_encode_bits(msg, nsym)
+    assert np.array_equal(_np(mvn.rs_encode(torch.tensor(msg, device=dev), nsym)), cw)
+    rx = cw.copy()
+    nbytes = cw.shape[1] // 8
+    for b in range(B):  # 0 .. capacity+2 corrupted symbols per word
+        for pos in rng.choice(nbytes, min(nbytes, b % (nsym // 2 + 3)), replace=False):
+            rx[b, 8 * pos: 8 * pos + 8] = rng.randint(0, 2, 8)
+    want, wst = oracle.rs_decode_bits(rx, nsym, want_status=True)
+    got, st = mvn.rs_decode(torch.tensor(rx, device=dev), nsym, return_status=True)
+    assert np.array_equal(_np(got), want) and np.array_equal(_np(st), wst)
+
+
+@pytest.mark.parametrize("coef", ["time_decay", "cost2100"])
+def test_by_word_va_rs_end_to_end_gpu(golden, dev, coef):
+    """G9: the reference's eval_by_word loop (VA detector with per-word channel, RS decode, per-block ser),
+    issued word by word with `count` like trainer.py:295 and as one batched call."""
+    g = golden("g9_by_word_va")
+    L, frames, sub, T, snr, fading, ttype, nsym = [int(v) for v in g[f"{coef}_meta"]]
+    det = mvn.VADetector(16, L, T, frames * sub, "ISI_AWGN", 0, bool(fading), ttype, {"train": "time_decay", "val": coef})
+    y = torch.tensor(g[f"{coef}_y"], device=dev)
+    tx = torch.tensor(g[f"{coef}_tx"].astype(np.float32), device=dev)
+    ref_det = g[f"{coef}_detected"].astype(np.float32)
+    batched = det(y, "val", snr, 0.2)  # 300 words, 300 channel rows: word i pairs with row i
+    assert np.array_equal(_np(batched), ref_det)
+    one_by_one = mvn.detect_by_word(det, y[:30], snr, 0.2, batched=False, pass_count=True)
+    assert np.array_equal(_np(one_by_one), ref_det[:30])
+    decoded = mvn.rs_decode(batched, nsym)
+    ser = (decoded != tx).float().mean(dim=1).cpu().numpy()
+    data = g[f"{coef}_data_indices"]
+    assert np.allclose(ser[data], g[f"{coef}_ser_by_word"][data], rtol=1e-6, atol=1e-7)
+    # re-encoding a decoded word (trainer.py:304) round-trips through the GPU encoder
+    reenc = mvn.rs_encode(decoded, nsym)
+    ok = (decoded == tx).all(dim=1)
+    assert torch.equal(reenc[ok][:, :120], tx[ok])
