@@ -131,6 +131,18 @@ int mvn_count_errors(const float *dec, int64_t dec_ld, const float *tx, int64_t 
                      mvn_stream_t stream);
 
 /*
+ * ISI-AWGN channel: ChannelModelDataset.transmit / ISIAWGNChannel.transmit,
+ * python_code/channel/channel_dataset.py:71,87-95 + channel.py:12-35 + modulator.py:12:
+ *   y[b,t] = sum_i h[b % Bh][L-1-i] * (1 - 2 c[b,t+i]) + sigma * w[b,t],   c = bits zero-padded past K,
+ * evaluated in float64 and stored fp32 (channel_dataset.py:103).  sigma = (10**(snr/10))**-0.5 (channel.py:23,31).
+ *   bits [B, ld_bits>=K] fp32 {0,1}; noise [B,T] standard-normal draws, float64 (noise_is_f64=1) or fp32, or NULL;
+ *   h [Bh, L] float64 taps (estimate_channel rows); y [B, y_ld>=T].  T is normally K (transmission length).
+ */
+int mvn_isi_awgn_transmit(const float *bits, int64_t ld_bits, int32_t K, const void *noise, int32_t noise_is_f64,
+                          const double *h, int64_t Bh, double sigma, float *y, int64_t y_ld, int64_t B, int32_t T,
+                          int32_t L, mvn_stream_t stream);
+
+/*
  * Reed-Solomon outer code, batched over words; bits are fp32 {0,1}, 8 per GF(2^8)
  * symbol, MSB first (np.packbits).  Same code and same behaviour past the correction capacity as
  * python_code/ecc/rs_main.py: encode (:9-18) / decode (:21-37) -- prim 0x11d, generator 2, nsym parity bytes,

@@ -58,3 +58,33 @@ class BPSKModulator:
     def modulate(c: np.ndarray) -> np.ndarray:
         """0 -> +1, 1 -> -1 (modulator.py:12)"""
         return 1 - 2 * c
+
+
+def transmit(bits, h: np.ndarray, snr: float, memory_length: int, noise=None):
+    """ISI-AWGN channel on the GPU (channel_dataset.py:71,87-95 + channel.py:12-35): `bits` [B,K] fp32 {0,1} codeword
+    bits on the device, `h` [Bh,L] float64 taps (row b % Bh is used for word b), `noise` [B,K] standard-normal draws
+    (torch float64/float32 tensor on the device) or None.  float64 arithmetic, fp32 result [B,K]."""
+    import torch
+
+    from . import _lib
+
+    _lib.require_gpu_tensor(bits, "bits")
+    c = bits.detach().to(torch.float32)
+    if c.stride(-1) != 1:
+        c = c.contiguous()
+    B, K = c.shape
+    hd = torch.as_tensor(np.ascontiguousarray(h, dtype=np.float64).reshape(-1, memory_length), device=c.device)
+    sigma = (10 ** (snr / 10)) ** (-0.5)  # channel.py:23,31
+    nz, is64 = None, 1
+    if noise is not None:
+        nz = noise.to(c.device).contiguous()
+        if nz.dtype not in (torch.float64, torch.float32) or tuple(nz.shape) != (B, K):
+            raise ValueError("noise must be a [B,K] float64/float32 tensor")
+        is64 = 1 if nz.dtype == torch.float64 else 0
+    y = torch.empty((B, K), dtype=torch.float32, device=c.device)
+    with torch.cuda.device(c.device):
+        rc = _lib.load().mvn_isi_awgn_transmit(_lib.ptr(c), c.stride(0), K, _lib.ptr(nz), is64, _lib.ptr(hd), hd.shape[0],
+                                               float(sigma), _lib.ptr(y), K, B, K, memory_length,
+                                               _lib.current_stream(c.device))
+    _lib.check(rc, "mvn_isi_awgn_transmit")
+    return y

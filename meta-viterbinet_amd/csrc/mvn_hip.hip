@@ -431,6 +431,31 @@ __global__ __launch_bounds__(256) void acs_block_kernel(const float *__restrict_
     if (argmin_j) argmin_j[e] = second ? 1 : 0;
 }
 
+// -------------------------------------------------------------------------------------------
+// ISI-AWGN channel: zero padding by L (channel_dataset.py:71), BPSK 1-2c (modulator.py:12),
+// anti-causal L-tap convolution + scaled white noise (channel.py:23-35), all in float64 like the reference's
+// NumPy code, stored fp32 like channel_dataset.py:103.  One thread per received sample.
+// -------------------------------------------------------------------------------------------
+template <typename NoiseT>
+__global__ __launch_bounds__(256) void isi_awgn_kernel(const float *__restrict__ bits, int64_t ld_bits, int K,
+                                                       const NoiseT *__restrict__ noise, const double *__restrict__ h,
+                                                       int64_t Bh, double sigma, float *__restrict__ y, int64_t y_ld,
+                                                       int64_t B, int T, int L) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * T) return;
+    const int64_t b = e / T;
+    const int t = (int)(e % T);
+    const double *hb = h + (b % Bh) * L;
+    double acc = 0.0;
+    for (int i = 0; i < L; ++i) {  // np.dot(h[:, ::-1], blockwise_s): row i of blockwise_s is s[t+i]
+        const int tt = t + i;
+        const double c = tt < K ? (double)bits[b * ld_bits + tt] : 0.0;
+        acc += hb[L - 1 - i] * (1.0 - 2.0 * c);
+    }
+    if (noise) acc += sigma * (double)noise[b * T + t];
+    y[b * y_ld + t] = (float)acc;
+}
+
 // MVN_UNFUSED=1 forces the two-kernel ViterbiNet path (MLP -> logits -> sweep) for testing.
 bool unfused_forced() {
     const char *e = getenv("MVN_UNFUSED");
@@ -647,6 +672,24 @@ int mvn_vnet_decode_count_f32(const float *y, int64_t y_ld, const float *W1, con
     if (!y || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !tx) return MVN_E_NULL;
     return launch_vnet16_fused(y, y_ld, W1, b1, W2, b2, W3, b3, dec, dec_ld, nullptr, nullptr, B, T, tx, tx_ld, K,
                                row_mask, (unsigned long long *)counters, (hipStream_t)stream);
+}
+
+int mvn_isi_awgn_transmit(const float *bits, int64_t ld_bits, int32_t K, const void *noise, int32_t noise_is_f64,
+                          const double *h, int64_t Bh, double sigma, float *y, int64_t y_ld, int64_t B, int32_t T,
+                          int32_t L, mvn_stream_t stream) {
+    if (B < 0 || T < 0 || K < 0 || L < 1 || L > 16 || ld_bits < K || y_ld < T || Bh < 1) return MVN_E_DIMS;
+    if (B == 0 || T == 0) return MVN_OK;
+    if (!bits || !h || !y) return MVN_E_NULL;
+    const int64_t n = B * (int64_t)T;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (noise_is_f64)
+        hipLaunchKernelGGL((isi_awgn_kernel<double>), dim3(grid), dim3(256), 0, st, bits, ld_bits, K, (const double *)noise,
+                           h, Bh, sigma, y, y_ld, B, T, L);
+    else
+        hipLaunchKernelGGL((isi_awgn_kernel<float>), dim3(grid), dim3(256), 0, st, bits, ld_bits, K, (const float *)noise, h,
+                           Bh, sigma, y, y_ld, B, T, L);
+    return (int)hipGetLastError();
 }
 
 int mvn_rs_decode_bits_f32(const float *rx_bits, int64_t ld_in, float *msg_bits, int64_t ld_out, int32_t *status,

@@ -13,7 +13,8 @@ import torch
 import torch.distributed as dist
 
 from . import metrics as _metrics
-from .channel import estimate_channel
+from .channel import estimate_channel, transmit
+from .ecc import rs_decode
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -39,13 +40,17 @@ def synthetic_words(n_words: int, block_length: int, memory_length: int, snr: fl
     g.manual_seed(seed)
     L = memory_length
     tx = torch.randint(0, 2, (n_words, block_length), generator=g, device=device, dtype=torch.int8).to(torch.float32)
-    s = 1.0 - 2.0 * torch.cat([tx, torch.zeros(n_words, L, device=device)], dim=1)
-    h = torch.tensor(estimate_channel(L, gamma, channel_coefficients)[0], dtype=torch.float32, device=device)
-    y = torch.zeros(n_words, block_length, device=device)
-    for k in range(L):
-        y += h[L - 1 - k] * s[:, k:k + block_length]
-    y += (10.0 ** (-snr / 20.0)) * torch.randn(n_words, block_length, generator=g, device=device)
-    return tx, y
+    h = estimate_channel(L, gamma, channel_coefficients)
+    noise = torch.randn(n_words, block_length, generator=g, device=device)
+    if torch.device(device).type == "cuda":
+        return tx, transmit(tx, h, snr, L, noise)  # mvn_isi_awgn_transmit
+    # CPU (host-side tests only): the same arithmetic in torch float64
+    s = 1.0 - 2.0 * torch.cat([tx, torch.zeros(n_words, L)], dim=1).double()
+    y = torch.zeros(n_words, block_length, dtype=torch.float64)
+    for i in range(L):
+        y += float(h[0, L - 1 - i]) * s[:, i:i + block_length]
+    y += ((10 ** (snr / 10)) ** (-0.5)) * noise.double()
+    return tx, y.float()
 
 
 def _gpu_counter(detected: torch.Tensor, tx: torch.Tensor, rows: Optional[torch.Tensor]) -> torch.Tensor:
@@ -54,11 +59,16 @@ def _gpu_counter(detected: torch.Tensor, tx: torch.Tensor, rows: Optional[torch.
 
 def eval_counters(detector: Callable, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma: float,
                   rows: Optional[torch.Tensor] = None, counter: Callable = _gpu_counter,
-                  group=None, reduce: bool = True) -> torch.Tensor:
-    """One Monte-Carlo point on THIS rank's rows: detect -> count -> (optionally) all-reduce.
+                  group=None, reduce: bool = True, n_symbols: int = 0, rs_decoder: Callable = rs_decode) -> torch.Tensor:
+    """One Monte-Carlo point on THIS rank's rows: detect -> [RS decode] -> count -> (optionally) all-reduce.
     `tx`/`rx` are the rank-local shards; `rows` are local row indices counted (None = all).
+    n_symbols > 0 = the reference's use_ecc path (trainer.py:234-236): detected words are RS-decoded (on the
+    device) before they are compared with the transmitted message bits.
     Returns int64[4] counters (global sums when reduce=True and a process group is up)."""
-    if counter is _gpu_counter and getattr(detector, "n_states", None) == 16 and hasattr(detector, "val_count"):
+    if n_symbols > 0:
+        detected = detector(rx, "val", snr, gamma)
+        counters = counter(rs_decoder(detected, n_symbols)[:, : tx.shape[1]], tx, rows)
+    elif counter is _gpu_counter and getattr(detector, "n_states", None) == 16 and hasattr(detector, "val_count"):
         counters = detector.val_count(rx, tx, rows)  # decode + count in one launch, decisions never stored
     else:
         detected = detector(rx, "val", snr, gamma)
@@ -70,17 +80,18 @@ def eval_counters(detector: Callable, tx: torch.Tensor, rx: torch.Tensor, snr: f
 
 def single_eval_at_point(detector: Callable, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma: float,
                          rows: Optional[torch.Tensor] = None, counter: Callable = _gpu_counter,
-                         group=None) -> Tuple[float, float, torch.Tensor]:
-    """trainer.py:222-241 without the data draw and the optional RS stage: returns (ser, fer, counters);
-    the reference returns ser only and drops fer (:238-241)."""
-    counters = eval_counters(detector, tx, rx, snr, gamma, rows, counter, group)
+                         group=None, n_symbols: int = 0) -> Tuple[float, float, torch.Tensor]:
+    """trainer.py:222-241 without the data draw: detect, optional RS decode (n_symbols > 0 = use_ecc), error
+    rates over the data rows.  Returns (ser, fer, counters); the reference returns ser only (:238-241)."""
+    counters = eval_counters(detector, tx, rx, snr, gamma, rows, counter, group, n_symbols=n_symbols)
     ser, fer = _metrics.rates_from_counters(counters)
     return ser, fer, counters
 
 
 def sharded_eval(detector: Callable, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma: float,
                  rows: Optional[torch.Tensor] = None, counter: Callable = _gpu_counter, group=None,
-                 rank: Optional[int] = None, world: Optional[int] = None) -> Tuple[float, float, torch.Tensor]:
+                 rank: Optional[int] = None, world: Optional[int] = None, n_symbols: int = 0,
+                 rs_decoder: Callable = rs_decode) -> Tuple[float, float, torch.Tensor]:
     """Same point, but given the FULL (tx, rx) on every rank: each rank takes its contiguous row shard
     (shard_range), maps the global `rows` filter into it, and the counters are all-reduced."""
     if rank is None:
@@ -94,7 +105,8 @@ def sharded_eval(detector: Callable, tx: torch.Tensor, rx: torch.Tensor, snr: fl
         r = r[(r >= lo) & (r < hi)] - lo
         local_rows = r.to(tx.device)
     if hi > lo:
-        counters = eval_counters(detector, tx[lo:hi], rx[lo:hi], snr, gamma, local_rows, counter, group, reduce=False)
+        counters = eval_counters(detector, tx[lo:hi], rx[lo:hi], snr, gamma, local_rows, counter, group, reduce=False,
+                                 n_symbols=n_symbols, rs_decoder=rs_decoder)
     else:
         counters = torch.zeros(4, dtype=torch.int64, device=tx.device)
     if dist.is_available() and dist.is_initialized():

@@ -47,6 +47,26 @@ def _oracle_counter(detected, tx, rows):
     return torch.tensor(oracle.count_errors(detected.numpy(), tx.numpy(), r))
 
 
+def _oracle_rs(detected, n_symbols):
+    import oracle
+
+    return torch.tensor(oracle.rs_decode_bits(detected.numpy(), n_symbols))
+
+
+def _coded_problem():
+    """24 message bytes-of-bits words, RS(5,3)-encoded, sent through the ISI channel at low noise."""
+    import oracle
+
+    rng = np.random.RandomState(3)
+    msg = rng.randint(0, 2, (21, 24)).astype(np.float32)
+    cw = oracle.rs_encode_bits(msg, 2)  # [21, 40]
+    L = 4
+    s = 1.0 - 2.0 * np.concatenate([cw, np.zeros((21, L), np.float32)], axis=1)
+    h = mvn.estimate_channel(L, 0.2, "time_decay")[0]
+    y = sum(h[L - 1 - k] * s[:, k:k + 40] for k in range(L)) + 0.25 * rng.normal(size=(21, 40))
+    return torch.tensor(msg), torch.tensor(y.astype(np.float32))
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -57,7 +77,11 @@ def _worker(rank, world, port, q):
         # rank-local shards + eval_counters (the bench.py pattern: each rank owns its rows) must agree too
         lo, hi = mvn.shard_range(tx.shape[0], rank, world)
         c2 = mvn.eval_counters(_oracle_detector(pri), tx[lo:hi], y[lo:hi], 8.0, 0.2, None, _oracle_counter)
-        q.put((rank, counters.tolist(), c2.tolist(), ser, fer))
+        # coded path (use_ecc): RS-decode the detected words before counting, sharded the same way
+        msg, cw_y = _coded_problem()
+        _, _, c3 = mvn.sharded_eval(_oracle_detector(pri), msg, cw_y, 8.0, 0.2, None, counter=_oracle_counter, n_symbols=2,
+                                    rs_decoder=_oracle_rs)
+        q.put((rank, counters.tolist(), c2.tolist(), ser, fer, c3.tolist()))
     finally:
         dist.destroy_process_group()
 
@@ -79,7 +103,12 @@ def test_world2_counters_equal_single_process():
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
-    for rank, counters, c2, ser, fer in res:
+    msg, cw_y = _coded_problem()
+    _, _, coded1 = mvn.sharded_eval(_oracle_detector(pri), msg, cw_y, 8.0, 0.2, None, counter=_oracle_counter, n_symbols=2,
+                                    rs_decoder=_oracle_rs, rank=0, world=1)
+    assert coded1[1] == 21 * 24
+    for rank, counters, c2, ser, fer, c3 in res:
         assert counters == c1.tolist()  # identical integers on every rank
         assert c2 == call.tolist()
         assert (ser, fer) == (ser1, fer1)
+        assert c3 == coded1.tolist()

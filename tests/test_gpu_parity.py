@@ -430,7 +430,33 @@ def test_by_word_va_rs_end_to_end_gpu(golden, dev, coef):
     ser = (decoded != tx).float().mean(dim=1).cpu().numpy()
     data = g[f"{coef}_data_indices"]
     assert np.allclose(ser[data], g[f"{coef}_ser_by_word"][data], rtol=1e-6, atol=1e-7)
+    # aggregated coded evaluation (single_eval_at_point with use_ecc, trainer.py:232-239) over the data rows
+    rows = torch.tensor(data, device=dev)
+    s_c, f_c, c = mvn.single_eval_at_point(det, tx, y, snr, 0.2, rows, n_symbols=nsym)
+    assert c.tolist()[1] == len(data) * 120
+    assert s_c == pytest.approx(float(np.mean(g[f"{coef}_ser_by_word"][data])), rel=1e-5)
     # re-encoding a decoded word (trainer.py:304) round-trips through the GPU encoder
     reenc = mvn.rs_encode(decoded, nsym)
     ok = (decoded == tx).all(dim=1)
     assert torch.equal(reenc[ok][:, :120], tx[ok])
+
+
+# ---------------------------------------------------------------- next #1: ISI-AWGN channel on the GPU
+@pytest.mark.parametrize("name", ["L4_static", "L4_fading1", "L4_fading2", "L4_cost2100", "L2_static", "L3_static",
+                                  "L8_static"])
+def test_channel_transmit_replays_reference_draw(golden, dev, name):
+    """Replays ChannelModelDataset.get_snr_data (channel_dataset.py:55-85): per word, bits from
+    RandomState(word_seed).randint and noise from RandomState(noise_seed).normal, channel row `index`; the GPU
+    channel kernel must reproduce the reference's received words bit for bit."""
+    g = golden("g2_va")
+    L, frames, sub, T, snr, fdec, ttype = [int(v) for v in g[f"{name}_meta"]]
+    W = frames * sub
+    rand_gen, word_gen = np.random.RandomState(3450002), np.random.RandomState(7860002)
+    bits = np.empty((W, T), np.float32)
+    noise = np.empty((W, T), np.float64)
+    for i in range(W):
+        bits[i] = word_gen.randint(0, 2, size=(1, T))
+        noise[i] = rand_gen.normal(0, 1, (1, T))
+    assert np.array_equal(bits, g[f"{name}_tx"].astype(np.float32))
+    y = mvn.transmit(torch.tensor(bits, device=dev), g[f"{name}_h"], snr, L, torch.tensor(noise, device=dev))
+    assert np.array_equal(_np(y), g[f"{name}_rx"])
