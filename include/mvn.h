@@ -131,6 +131,24 @@ int mvn_count_errors(const float *dec, int64_t dec_ld, const float *tx, int64_t 
                      mvn_stream_t stream);
 
 /*
+ * Online (self-supervised) training of the ViterbiNet MLP on ONE word, all iterations in one launch
+ * (SURVEY 8f next #3): VNETTrainer.online_training, python_code/trainers/VNET/vnet_trainer.py:49-60 ->
+ * Trainer.run_train_loop, trainers/trainer.py:492-505 with CrossEntropyLoss(mean) and torch.optim.Adam
+ * (amsgrad off, no weight decay), i.e. n_iter x { logits = net(y); loss = CE(logits[idx_i], labels[idx_i]);
+ * backward; Adam.step }.
+ *   y [T] received word; labels [T] int32 trellis states (calculate_states, trellis_utils.py:33-46);
+ *   batch_idx [n_iter, M] int32 sample indices per iteration (select_batch, trainer.py:534-544), or NULL = all T
+ *   samples every iteration (metavnet_trainer.py:41-50);
+ *   W1..b3: parameters, updated in place; adam_m/adam_v: [P] exp_avg / exp_avg_sq in parameter order
+ *   (P = 250 + 50*100 + 51*S), updated in place; step0 = Adam steps already taken;
+ *   loss_out [n_iter] or NULL.  S <= 32.  fp32; agrees with torch autograd + Adam to rounding, not bitwise.
+ */
+int mvn_vnet_online_train_f32(const float *y, const int32_t *labels, int32_t T, const int32_t *batch_idx, int32_t M,
+                              int32_t n_iter, float *W1, float *b1, float *W2, float *b2, float *W3, float *b3,
+                              float *adam_m, float *adam_v, int64_t step0, float lr, float beta1, float beta2, float eps,
+                              float *loss_out, int32_t S, mvn_stream_t stream);
+
+/*
  * ISI-AWGN channel: ChannelModelDataset.transmit / ISIAWGNChannel.transmit,
  * python_code/channel/channel_dataset.py:71,87-95 + channel.py:12-35 + modulator.py:12:
  *   y[b,t] = sum_i h[b % Bh][L-1-i] * (1 - 2 c[b,t+i]) + sigma * w[b,t],   c = bits zero-padded past K,

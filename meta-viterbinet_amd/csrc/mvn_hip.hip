@@ -372,6 +372,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 #include "vnet16_fused.inc"
 #include "sweep16_rows.inc"
 #include "rs_codec.inc"
+#include "online_train.inc"
 
 // -------------------------------------------------------------------------------------------
 // metrics.py:7-17 as integer counters.  One wave per row, block-level reduction, one atomic
@@ -672,6 +673,24 @@ int mvn_vnet_decode_count_f32(const float *y, int64_t y_ld, const float *W1, con
     if (!y || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !tx) return MVN_E_NULL;
     return launch_vnet16_fused(y, y_ld, W1, b1, W2, b2, W3, b3, dec, dec_ld, nullptr, nullptr, B, T, tx, tx_ld, K,
                                row_mask, (unsigned long long *)counters, (hipStream_t)stream);
+}
+
+int mvn_vnet_online_train_f32(const float *y, const int32_t *labels, int32_t T, const int32_t *batch_idx, int32_t M,
+                              int32_t n_iter, float *W1, float *b1, float *W2, float *b2, float *W3, float *b3,
+                              float *adam_m, float *adam_v, int64_t step0, float lr, float beta1, float beta2, float eps,
+                              float *loss_out, int32_t S, mvn_stream_t stream) {
+    if (T < 1 || n_iter < 0 || step0 < 0 || (batch_idx && M < 1)) return MVN_E_DIMS;
+    if (!valid_states(S) || S > 32) return MVN_E_STATES;  // parameters + Adam moments must fit the 160-KB LDS
+    if (n_iter == 0) return MVN_OK;
+    if (!y || !labels || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !adam_m || !adam_v) return MVN_E_NULL;
+    const size_t lds = online_train_lds_bytes(S);
+    hipError_t e = hipFuncSetAttribute((const void *)online_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(online_train_kernel, dim3(1), dim3(kTrainThreads), lds, (hipStream_t)stream, y, labels, T, batch_idx,
+                       M, n_iter, W1, b1, W2, b2, W3, b3, adam_m, adam_v, (long long)step0, lr, beta1, beta2, eps, loss_out,
+                       S);
+    return (int)hipGetLastError();
 }
 
 int mvn_isi_awgn_transmit(const float *bits, int64_t ld_bits, int32_t K, const void *noise, int32_t noise_is_f64,

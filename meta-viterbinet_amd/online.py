@@ -1,0 +1,63 @@
+"""Online (self-supervised) training of the ViterbiNet MLP in ONE kernel launch per word: counterpart of
+VNETTrainer.online_training (python_code/trainers/VNET/vnet_trainer.py:49-60) / run_train_loop (trainers/trainer.py:492-505)
+with CrossEntropyLoss + Adam, the step that dominates the by-word evaluation with self_supervised=True."""
+import torch
+
+from . import _lib
+from .trellis import calculate_states
+
+
+class OnlineTrainer:
+    """Holds the Adam state (exp_avg, exp_avg_sq, step) for a VNETDetector's six parameters, like the optimizer
+    deep_learning_setup() creates (trainer.py:163-173), and runs `iterations` CE+Adam steps on one word on the GPU."""
+
+    def __init__(self, detector, memory_length: int, lr: float = 0.001, betas=(0.9, 0.999), eps: float = 1e-8,
+                 train_minibatch_size: int = 32):
+        self.detector = detector
+        self.memory_length = memory_length
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.train_minibatch_size = train_minibatch_size
+        self.params = list(detector.net.parameters())
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.step = 0
+
+    def select_batches(self, T: int, iterations: int) -> torch.Tensor:
+        """`iterations` minibatches drawn like select_batch (trainer.py:542): torch.multinomial with weights
+        arange(T) (sample 0 is never drawn), without replacement, all iterations in one call."""
+        dev = self.params[0].device
+        w = torch.arange(T, dtype=torch.float32, device=dev).expand(iterations, T)
+        return torch.multinomial(w, self.train_minibatch_size).to(torch.int32)
+
+    def online_training(self, tx: torch.Tensor, rx: torch.Tensor, iterations: int = 200, batch_idx: torch.Tensor = None,
+                        full_word: bool = False, return_loss: bool = False):
+        """tx [1,T] (re-encoded / detected word), rx [1,T] received word (vnet_trainer.py:49-60).
+        full_word=True uses every sample each iteration (the Meta-ViterbiNet variant, metavnet_trainer.py:41-64)."""
+        p = self.params
+        dev = p[0].device
+        _lib.require_gpu_tensor(rx, "rx")
+        y = rx.detach().to(torch.float32).reshape(-1).contiguous()
+        T = y.numel()
+        labels = calculate_states(self.memory_length, tx.detach().to(dev).reshape(1, -1)).to(torch.int32).contiguous()
+        if full_word:
+            idx, M = None, 0
+        else:
+            idx = (self.select_batches(T, iterations) if batch_idx is None else batch_idx.to(device=dev, dtype=torch.int32)).contiguous()
+            M = idx.shape[1]
+            if idx.shape[0] != iterations:
+                raise ValueError("batch_idx must be [iterations, M]")
+        for t in p:
+            if not t.data.is_contiguous() or t.dtype != torch.float32:
+                raise ValueError("ViterbiNet parameters must be contiguous fp32")
+        loss = torch.empty(iterations, dtype=torch.float32, device=dev) if return_loss else None
+        S = p[5].numel()
+        with torch.cuda.device(dev):
+            rc = _lib.load().mvn_vnet_online_train_f32(_lib.ptr(y), _lib.ptr(labels), T, _lib.ptr(idx), M, iterations,
+                                                       *[_lib.ptr(t.data) for t in p], _lib.ptr(self.exp_avg),
+                                                       _lib.ptr(self.exp_avg_sq), self.step, self.lr, self.betas[0],
+                                                       self.betas[1], self.eps, _lib.ptr(loss), S, _lib.current_stream(dev))
+        _lib.check(rc, "mvn_vnet_online_train_f32")
+        self.step += iterations
+        return loss

@@ -369,6 +369,55 @@ def g9_by_word_va():
     save("g9_by_word_va", **out)
 
 
+# ----------------------------------------------------------------------------- G10
+def g10_online_training():
+    """VNETTrainer.online_training (vnet_trainer.py:49-60) for a few iterations, with the minibatch indices that
+    select_batch drew (torch.multinomial is wrapped to record them): initial/final weights and per-iteration loss."""
+    torch.manual_seed(77)
+    torch.set_num_threads(1)
+    tr = VNETTrainer(use_ecc=True, n_symbols=2, memory_length=4, val_block_length=120, val_frames=1,
+                     subframes_in_frame=3, train_block_length=120, train_frames=1, train_minibatch_num=1,
+                     channel_coefficients="time_decay", fading_in_channel=False, fading_in_decoder=False,
+                     noisy_est_var=0, val_SNR_start=10, val_SNR_end=10, gamma=0.2, weights_dir=TMP,
+                     self_supervised=True, self_supervised_iterations=25, eval_mode="by_word",
+                     noise_seed=3450002, word_seed=7860002)
+    tr.deep_learning_setup()
+    from python_code.ecc.rs_main import encode
+
+    tx_msg, rx = tr.channel_dataset["val"].__getitem__(snr_list=[10], gamma=0.2)
+    tx = torch.Tensor(encode(tx_msg[1].int().numpy(), 2).reshape(1, -1))
+    rxw = rx[1].reshape(1, -1)
+    w0 = export_weights(tr.detector)
+    rec, losses = [], []
+    real_multinomial = torch.multinomial
+
+    def spy(weights, n, *a, **k):
+        r = real_multinomial(weights, n, *a, **k)
+        rec.append(r.numpy().copy())
+        return r
+
+    real_loop = tr.run_train_loop
+
+    def loop_spy(soft_estimation, transmitted_words):
+        v = real_loop(soft_estimation=soft_estimation, transmitted_words=transmitted_words)
+        losses.append(v)
+        return v
+
+    torch.multinomial = spy
+    tr.run_train_loop = loop_spy
+    try:
+        tr.online_training(tx, rxw)
+    finally:
+        torch.multinomial = real_multinomial
+    w1 = export_weights(tr.detector)
+    out = {"tx": tx.numpy().astype(np.uint8), "rx": rxw.numpy(), "idx": np.array(rec, np.int32),
+           "loss": np.array(losses, np.float64), "lr": np.array(tr.lr)}
+    for i in range(6):
+        out[f"w0_{i}"], out[f"w1_{i}"] = w0[i], w1[i]
+    print("online training: iterations", len(rec), "loss", losses[0], "->", losses[-1])
+    save("g10_online_training", **out)
+
+
 # ----------------------------------------------------------------------------- G8
 def g8_rs():
     """RS(n,k) KATs through the reference's own encode/decode (rs_main.py:9-37), incl. patterns beyond the
@@ -418,6 +467,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g8":
         g8_rs()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g10":
+        g10_online_training()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g9":
         import contextlib
         import io
@@ -439,6 +491,7 @@ if __name__ == "__main__":
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         g9_by_word_va()
+        g10_online_training()
         g7_by_word(trained4)
     print("\n".join(l for l in buf.getvalue().splitlines() if l.startswith(("time_decay", "cost2100", "wrote", "Final"))))
     print("torch", torch.__version__, "numpy", np.__version__)

@@ -460,3 +460,82 @@ def test_channel_transmit_replays_reference_draw(golden, dev, name):
     assert np.array_equal(bits, g[f"{name}_tx"].astype(np.float32))
     y = mvn.transmit(torch.tensor(bits, device=dev), g[f"{name}_h"], snr, L, torch.tensor(noise, device=dev))
     assert np.array_equal(_np(y), g[f"{name}_rx"])
+
+
+# ---------------------------------------------------------------- next #3: online (self-supervised) training in one launch
+def _torch_online_ref(w, y, labels, idx, lr, n_iter, full_word=False):
+    """The reference's arithmetic for run_train_loop (trainer.py:492-505): torch autograd, CrossEntropyLoss(mean),
+    torch.optim.Adam, on CPU in fp32.  (A torch reference is the right oracle for this floating-point kernel.)"""
+    net = torch.nn.Sequential(torch.nn.Linear(1, 100), torch.nn.Sigmoid(), torch.nn.Linear(100, 50), torch.nn.ReLU(),
+                              torch.nn.Linear(50, w[4].shape[0]))
+    with torch.no_grad():
+        for p, a in zip(net.parameters(), w):
+            p.copy_(torch.tensor(a))
+    opt = torch.optim.Adam(net.parameters(), lr=lr)
+    crit = torch.nn.CrossEntropyLoss()
+    losses = []
+    yt, lt = torch.tensor(y).reshape(-1, 1), torch.tensor(labels).long()
+    for it in range(n_iter):
+        logits = net(yt)
+        loss = crit(logits, lt) if full_word else crit(logits[torch.tensor(idx[it]).long()], lt[torch.tensor(idx[it]).long()])
+        for p in net.parameters():
+            p.grad = None
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    return [p.detach().numpy() for p in net.parameters()], np.array(losses)
+
+
+def test_online_training_golden(golden, dev):
+    """G10: 25 iterations of VNETTrainer.online_training in the reference (its own minibatch draws recorded).
+    Tolerance: parameters |d| <= 2e-5 + 1e-3*|w| and per-iteration loss relative 1e-4 -- reduction order differs
+    from torch's, Adam's m/sqrt(v) amplifies last-bit gradient differences."""
+    g = golden("g10_online_training")
+    S, T = 16, 136
+    det = _vnet_with([g[f"w0_{i}"] for i in range(6)], S, T, dev)
+    tr = mvn.OnlineTrainer(det, 4, lr=float(g["lr"]))
+    idx = torch.tensor(g["idx"], device=dev)
+    loss = tr.online_training(torch.tensor(g["tx"].astype(np.float32), device=dev), torch.tensor(g["rx"], device=dev),
+                              iterations=idx.shape[0], batch_idx=idx, return_loss=True)
+    assert np.allclose(_np(loss), g["loss"], rtol=1e-4, atol=1e-6)
+    for i, p in enumerate(det.net.parameters()):
+        ref = g[f"w1_{i}"]
+        assert np.all(np.abs(_np(p) - ref) <= 2e-5 + 1e-3 * np.abs(ref)), i
+    assert tr.step == idx.shape[0]
+    # the trained detector still decodes through the HIP path (weights are read at call time)
+    assert det(torch.tensor(g["rx"], device=dev), "val").shape == (1, T)
+
+
+@pytest.mark.parametrize("n_iter,full_word", [(1, False), (6, False), (40, False), (3, True)])
+def test_online_training_vs_torch(dev, n_iter, full_word):
+    S, T, L = 16, 136, 4
+    rng = np.random.RandomState(n_iter)
+    w = _rand_weights(S, rng)
+    tx = rng.randint(0, 2, (1, T)).astype(np.float32)
+    y = rng.normal(0, 1.5, (1, T)).astype(np.float32)
+    labels = mvn.calculate_states(L, torch.tensor(tx)).numpy()
+    idx = np.stack([rng.choice(np.arange(1, T), 32, replace=False) for _ in range(n_iter)]).astype(np.int32)
+    ref_w, ref_loss = _torch_online_ref(w, y[0], labels, idx, 1e-3, n_iter, full_word)
+    det = _vnet_with(w, S, T, dev)
+    tr = mvn.OnlineTrainer(det, L)
+    # two calls: the Adam state (moments, step count) must carry over between words like the reference's optimizer
+    n1 = n_iter // 2
+    l1 = tr.online_training(torch.tensor(tx, device=dev), torch.tensor(y, device=dev), iterations=n1,
+                            batch_idx=torch.tensor(idx[:n1], device=dev), full_word=full_word, return_loss=True) if n1 else None
+    l2 = tr.online_training(torch.tensor(tx, device=dev), torch.tensor(y, device=dev), iterations=n_iter - n1,
+                            batch_idx=torch.tensor(idx[n1:], device=dev), full_word=full_word, return_loss=True)
+    loss = np.concatenate([_np(l1), _np(l2)]) if n1 else _np(l2)
+    assert np.allclose(loss, ref_loss, rtol=2e-4, atol=1e-6)
+    for i, p in enumerate(det.net.parameters()):
+        assert np.all(np.abs(_np(p) - ref_w[i]) <= 2e-5 + 1e-3 * np.abs(ref_w[i])), i
+
+
+def test_online_training_draws_like_select_batch(dev):
+    det = mvn.VNETDetector(16, {"train": 136, "val": 136}).to(dev)
+    tr = mvn.OnlineTrainer(det, 4)
+    idx = tr.select_batches(136, 50)
+    assert idx.shape == (50, 32) and int(idx.min()) >= 1 and int(idx.max()) <= 135  # sample 0 has weight 0 (trainer.py:542)
+    assert all(len(set(r.tolist())) == 32 for r in idx)  # without replacement
+    before = [p.detach().clone() for p in det.parameters()]
+    tr.online_training(torch.zeros(1, 136, device=dev), torch.randn(1, 136, device=dev), iterations=5)
+    assert any(not torch.equal(a, b) for a, b in zip(before, det.parameters()))
