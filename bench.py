@@ -205,10 +205,10 @@ def main():
                          "traffic": measured_traffic("vnet16_fused_kernel<false>", B), "traffic_unit": "HBM bytes/launch",
                          "algorithmic_hbm_bytes": 8.0 * B * T,
                          "ms_per_launch": ms_fused, "flop_per_symbol": FLOP_PER_SYMBOL},
-            "roofline_acs_sweep": {"kernel": "sweep16_rows_kernel<COST> (mvn_acs_sweep_f32)", "bound": "hbm",
+            "roofline_acs_sweep": {"kernel": "sweep16_lds_kernel<COST> (mvn_acs_sweep_f32, LDS-DMA streamed costs)", "bound": "hbm",
                                    "achieved": acs_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                    "frac": acs_gbps / PEAK_HBM_GBPS,
-                                   "traffic": measured_traffic("sweep16_rows_kernel<0>", B),
+                                   "traffic": measured_traffic("sweep16_lds_kernel<0>", B),
                                    "traffic_unit": "HBM bytes/launch", "algorithmic_hbm_bytes": ACS_BYTES_PER_SYMBOL * B * T,
                                    "ms_per_launch": ms_acs,
                                    "bytes_per_symbol": ACS_BYTES_PER_SYMBOL},

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmvn_hip.so")
+LIB_PATH = os.environ.get("MVN_LIB_PATH", os.path.join(_PKG, "libmvn_hip.so"))  # override: A/B builds
 ABI_VERSION = 1
 
 _vp = ctypes.c_void_p

@@ -15,6 +15,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "../../include/mvn.h"
 
 namespace {
@@ -371,6 +373,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 
 #include "vnet16_fused.inc"
 #include "sweep16_rows.inc"
+#include "sweep16_lds.inc"
 #include "rs_codec.inc"
 #include "online_train.inc"
 
@@ -528,8 +531,13 @@ bool generic_sweep_forced() {
 template <int MODE>
 int dispatch_sweep(const float *src, int64_t src_ld, const float *priors, int64_t Bp, float *dec, int64_t dec_ld,
                    float *final_metric, int64_t B, int T, int S, hipStream_t st) {
-    if (S == 16 && !generic_sweep_forced())
+    if (S == 16 && !generic_sweep_forced()) {
+        if constexpr (MODE != MODE_VA) {  // materialised costs: stream them through LDS in 1-KB pieces
+            const char *e = getenv("MVN_SWEEP16");  // "rows" = register-prefetch variant (A/B, tests)
+            if (!(e && e[0] == 'r')) return launch_sweep16_lds<MODE>(src, dec, dec_ld, final_metric, B, T, st);
+        }
         return launch_sweep16_rows<MODE>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
+    }
     return launch_sweep<MODE>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, S, st);
 }
 

@@ -236,7 +236,7 @@ def test_vnet16_fused_and_unfused_paths(oracle, dev, monkeypatch, B, T):
                 assert np.array_equal(_np(lg), rlg)
 
 
-@pytest.mark.parametrize("B,T", [(1, 1), (3, 15), (4, 16), (5, 17), (67, 129), (130, 1000)])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 15), (4, 16), (5, 17), (2, 33), (7, 48), (9, 49), (67, 129), (130, 1000)])
 def test_sweep16_rows_and_generic_paths(oracle, dev, monkeypatch, B, T):
     """S=16 has a dedicated row-per-block DPP sweep; MVN_GENERIC_SWEEP=1 forces the generic LDS sweep.
     Sweep over costs and fused VA must both match the oracle on either path."""
@@ -249,8 +249,9 @@ def test_sweep16_rows_and_generic_paths(oracle, dev, monkeypatch, B, T):
     rdec, rfm = oracle.acs_sweep(cost)
     vdec, vfm = oracle.va_decode(y, pri)
     ct, yt, pt = torch.tensor(cost, device=dev), torch.tensor(y, device=dev), torch.tensor(pri, device=dev)
-    for generic in ("0", "1"):
+    for generic, variant in (("0", "lds"), ("0", "rows"), ("1", "lds")):
         monkeypatch.setenv("MVN_GENERIC_SWEEP", generic)
+        monkeypatch.setenv("MVN_SWEEP16", variant)  # LDS-DMA streaming vs register-prefetch row sweep
         dec, fm = mvn.acs_sweep(ct, return_final=True)
         assert np.array_equal(_np(dec), rdec) and np.array_equal(_np(fm), rfm), generic
         d2 = torch.zeros_like(yt)
