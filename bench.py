@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=10000, help="blocks per GPU (BASELINE configs[1]: 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-fused-count", action="store_true", help="(profiling) keep every fused-kernel dispatch decode-only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -176,7 +177,7 @@ def main():
                                5, dev)
         ms_step = event_time_ms(step, 3, dev)
         cfused = torch.zeros(4, dtype=torch.int64, device=dev)
-        ms_fused_count = event_time_ms(lambda: det.val_count(y, tx, None, cfused), 5, dev)
+        ms_fused_count = float("nan") if args.skip_fused_count else event_time_ms(lambda: det.val_count(y, tx, None, cfused), 5, dev)
         del cost
         mlp_tflops = FLOP_PER_SYMBOL * B * T / (ms_fused * 1e-3) / 1e12
         acs_gbps = ACS_BYTES_PER_SYMBOL * B * T / (ms_acs * 1e-3) / 1e9
@@ -199,10 +200,10 @@ def main():
                        "parallelism": f"block-sharded x{world}, one all-reduce of int64[4] counters"},
             "ser_at_snr": ser,
             "fer_at_snr": fer,
-            "roofline": {"kernel": "vnet16_fused_kernel<false> (ViterbiNet MLP on f32 MFMA 16x16x4 + in-place DPP trellis sweep)", "bound": "mfma",
+            "roofline": {"kernel": "vnet16_fused_kernel<false,true> (ViterbiNet MLP on f32 MFMA 16x16x4 + in-place DPP trellis sweep)", "bound": "mfma",
                          "achieved": mlp_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": mlp_tflops / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": measured_traffic("vnet16_fused_kernel<false>", B), "traffic_unit": "HBM bytes/launch",
+                         "traffic": measured_traffic("vnet16_fused_kernel<false, true>", B), "traffic_unit": "HBM bytes/launch",
                          "algorithmic_hbm_bytes": 8.0 * B * T,
                          "ms_per_launch": ms_fused, "flop_per_symbol": FLOP_PER_SYMBOL},
             "roofline_acs_sweep": {"kernel": "sweep16_lds_kernel<COST> (mvn_acs_sweep_f32, LDS-DMA streamed costs)", "bound": "hbm",

@@ -10,7 +10,7 @@ mkdir -p "$R/$OUT"
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   tag=$(echo $C | tr ' ' '_')
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$R/$OUT/$tag" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$R/$OUT/$tag" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --skip-fused-count > /dev/null 2>&1
 done
 python3 "$R/tools/pmc_summarize.py" "$R/$OUT" > "$R/$OUT/summary.csv"
 cat "$R/$OUT/summary.csv"
