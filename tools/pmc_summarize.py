@@ -18,4 +18,4 @@ print("kernel,counter,mean_per_dispatch,dispatches")
 for k in sorted(agg):
     for c in sorted(agg[k]):
         v = agg[k][c]
-        print(f"{k},{c},{sum(v)/len(v):.1f},{len(v)}")
+        print(f"\"{k}\",{c},{sum(v)/len(v):.1f},{len(v)}")
