@@ -14,7 +14,7 @@ import torch.distributed as dist
 
 from . import metrics as _metrics
 from .channel import estimate_channel, transmit
-from .ecc import rs_decode
+from .ecc import rs_decode, rs_encode
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -127,3 +127,38 @@ def detect_by_word(detector: Callable, rx: torch.Tensor, snr: float, gamma: floa
         word = rx[count].reshape(1, -1)
         outs.append(detector(word, "val", snr, gamma, count) if pass_count else detector(word, "val", snr, gamma))
     return torch.cat(outs, dim=0)
+
+
+def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma: float, n_symbols: int,
+                 subframes_in_frame: int, self_supervised: bool = False, online_trainer=None,
+                 self_supervised_iterations: int = 200, ser_thresh: float = 0.02, pass_count: bool = False,
+                 verbose: bool = False) -> np.ndarray:
+    """Sequential per-block online evaluation: counterpart of Trainer.eval_by_word (trainer.py:267-354) with
+    buffer_empty=True and online_meta=False.  Everything but the control flow stays on the GPU:
+        for every block k:  detect (B=1)  ->  data block: RS decode, ser, RS re-encode | pilot: encode the known word
+                            ->  if ser <= ser_thresh: keep (rx, label) where label = detected word if ser > 0 else the
+                                re-encoded word  ->  if self_supervised: online_trainer.online_training(label, rx)
+    tx [N, K] message bits, rx [N, K + 8*n_symbols] received words; block k is a pilot when k % subframes_in_frame == 0
+    (trainer.py:100-102).  Returns ser_by_word [N] (0 for pilots), like the reference.
+    One host sync per block (the ser decides whether to train), as in the reference (trainer.py:305)."""
+    N = tx.shape[0]
+    ser_by_word = np.zeros(N)
+    if self_supervised and online_trainer is None:
+        raise ValueError("self_supervised=True needs an OnlineTrainer")
+    for count in range(N):
+        transmitted_word, received_word = tx[count].reshape(1, -1), rx[count].reshape(1, -1)
+        detected_word = detector(received_word, "val", snr, gamma, count) if pass_count else detector(received_word, "val", snr, gamma)
+        if count % subframes_in_frame != 0:
+            decoded_word = rs_decode(detected_word, n_symbols)
+            ser = float((decoded_word != transmitted_word).float().mean().item())  # calculate_error_rates (:301)
+            encoded_word = rs_encode(decoded_word, n_symbols)  # :304
+            ser_by_word[count] = ser
+        else:
+            encoded_word = rs_encode(transmitted_word, n_symbols)  # pilot: the word is known (:314-316)
+            ser = 0.0
+        if verbose:
+            print(f"current: {count, ser}")
+        if ser <= ser_thresh and self_supervised:
+            label = detected_word if ser > 0 else encoded_word  # :321-324
+            online_trainer.online_training(label, received_word, iterations=self_supervised_iterations)  # :345-347
+    return ser_by_word

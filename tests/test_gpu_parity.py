@@ -540,3 +540,43 @@ def test_online_training_draws_like_select_batch(dev):
     before = [p.detach().clone() for p in det.parameters()]
     tr.online_training(torch.zeros(1, 136, device=dev), torch.randn(1, 136, device=dev), iterations=5)
     assert any(not torch.equal(a, b) for a, b in zip(before, det.parameters()))
+
+
+# ---------------------------------------------------------------- a12: the whole eval_by_word loop
+@pytest.mark.parametrize("coef", ["time_decay", "cost2100"])
+def test_eval_by_word_loop_va_golden(golden, dev, coef):
+    """harness.eval_by_word (sequential, with `count`) reproduces the reference's ser_by_word (G9) for every block."""
+    g = golden("g9_by_word_va")
+    L, frames, sub, T, snr, fading, ttype, nsym = [int(v) for v in g[f"{coef}_meta"]]
+    det = mvn.VADetector(16, L, T, frames * sub, "ISI_AWGN", 0, bool(fading), ttype, {"train": "time_decay", "val": coef})
+    y = torch.tensor(g[f"{coef}_y"], device=dev)
+    tx = torch.tensor(g[f"{coef}_tx"].astype(np.float32), device=dev)
+    ser = mvn.eval_by_word(det, tx, y, snr, 0.2, nsym, sub, pass_count=True)
+    assert np.allclose(ser, g[f"{coef}_ser_by_word"], rtol=1e-6, atol=1e-7)
+
+
+def test_eval_by_word_self_supervised_tracks_channel(golden, dev):
+    """Self-supervised online training (vnet_trainer.py:49-60 inside trainer.py:345-347) on a fading channel that
+    drifts away from the one the weights were trained on (time_decay, fading type 2, 300 blocks, RS(17,15)): with the HIP
+    online-training kernel in the loop the mean coded ser over the last 200 blocks must not be worse than the frozen
+    detector's, and the detector must actually have been updated.  Statistical check only -- the reference's minibatch
+    draws are unseeded."""
+    g7 = golden("g7_by_word")
+    w = [g7[f"w{i}"] for i in range(6)]
+    N, K, nsym, L, snr = 300, 120, 2, 4, 10.0
+    gen = torch.Generator(device=dev).manual_seed(5)
+    msg = torch.randint(0, 2, (N, K), generator=gen, device=dev).float()
+    cw = mvn.rs_encode(msg, nsym)
+    h = np.concatenate([mvn.estimate_channel(L, 0.2, "time_decay", fading=True, index=i, fading_taps_type=2) for i in range(N)])
+    y = mvn.transmit(cw, h, snr, L, torch.randn(N, K + 8 * nsym, generator=gen, device=dev))
+    det0 = _vnet_with(w, 16, K + 8 * nsym, dev)
+    ser_frozen = mvn.eval_by_word(det0, msg, y, snr, 0.2, nsym, 25)
+    det1 = _vnet_with(w, 16, K + 8 * nsym, dev)
+    tr = mvn.OnlineTrainer(det1, L)
+    torch.manual_seed(0)
+    ser_online = mvn.eval_by_word(det1, msg, y, snr, 0.2, nsym, 25, self_supervised=True, online_trainer=tr,
+                                  self_supervised_iterations=100)
+    assert tr.step >= 100 * 100  # most blocks pass the ser threshold and trigger training
+    assert any(not torch.equal(a, b) for a, b in zip(det0.parameters(), det1.parameters()))
+    print("mean ser frozen", ser_frozen[100:].mean(), "online", ser_online[100:].mean())
+    assert ser_online[100:].mean() <= ser_frozen[100:].mean() + 2e-3
