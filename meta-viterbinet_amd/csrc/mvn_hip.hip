@@ -374,6 +374,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 #include "vnet16_fused.inc"
 #include "sweep16_rows.inc"
 #include "sweep16_lds.inc"
+#include "va256_inplace.inc"
 #include "rs_codec.inc"
 #include "online_train.inc"
 
@@ -537,6 +538,10 @@ int dispatch_sweep(const float *src, int64_t src_ld, const float *priors, int64_
             if (!(e && e[0] == 'r')) return launch_sweep16_lds<MODE>(src, dec, dec_ld, final_metric, B, T, st);
         }
         return launch_sweep16_rows<MODE>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
+    }
+    if constexpr (MODE == MODE_VA) {
+        if (S == 256 && !generic_sweep_forced())
+            return launch_va256_inplace(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
     }
     return launch_sweep<MODE>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, S, st);
 }
