@@ -162,6 +162,18 @@ def main():
     total_symbols = float(world) * B * T * args.steps
     ser, fer = mvn.rates_from_counters(counters)
 
+    # FER@SNR / SER@SNR curve (the second half of BASELINE's metric), outside the timed region: fresh words per SNR
+    # point on every rank, fused decode+count, one all-reduce of the int64[4] counters per point.
+    fer_curve = []
+    for snr_db in (7.0, 8.0, 9.0, 10.0, 11.0, 12.0):  # plotter_main.py:117-122 sweeps 7..12 dB
+        txs, ys = mvn.synthetic_words(B, T, L, snr_db, GAMMA, dev, seed=7860002 + 100 * int(snr_db) + rank)
+        c = det.val_count(ys, txs)
+        if world > 1:
+            all_reduce(c)
+        s_, f_ = mvn.rates_from_counters(c)
+        fer_curve.append({"snr_db": snr_db, "ser": s_, "fer": f_, "frames": int(c[3].item())})
+    del txs, ys
+
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel, timed alone with HIP events on its launch stream
@@ -200,6 +212,7 @@ def main():
                        "parallelism": f"block-sharded x{world}, one all-reduce of int64[4] counters"},
             "ser_at_snr": ser,
             "fer_at_snr": fer,
+            "fer_curve": fer_curve,
             "roofline": {"kernel": "vnet16_fused_kernel<false,true> (ViterbiNet MLP on f32 MFMA 16x16x4 + in-place DPP trellis sweep)", "bound": "mfma",
                          "achieved": mlp_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": mlp_tflops / PEAK_F32_MFMA_TFLOPS,
