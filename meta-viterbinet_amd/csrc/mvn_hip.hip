@@ -398,8 +398,18 @@ __global__ __launch_bounds__(256) void count_errors_kernel(const float *__restri
     for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n_rows; i += (int64_t)gridDim.x * 4) {
         const int64_t r = rows ? rows[i] : i;
         int e = 0;
-        for (int k = lane; k < K; k += 64)
-            e += ((long long)dec[r * dec_ld + k] != (long long)tx[r * tx_ld + k]) ? 1 : 0;  // .long() then eq
+        const float *dr = dec + r * dec_ld, *tr = tx + r * tx_ld;
+        if ((((uintptr_t)dr | (uintptr_t)tr) & 15) == 0) {  // 16-B aligned rows: 4 symbols per load
+            const int K4 = K >> 2;
+            for (int k = lane; k < K4; k += 64) {
+                const float4 a = reinterpret_cast<const float4 *>(dr)[k], c = reinterpret_cast<const float4 *>(tr)[k];
+                e += ((long long)a.x != (long long)c.x) + ((long long)a.y != (long long)c.y) +
+                     ((long long)a.z != (long long)c.z) + ((long long)a.w != (long long)c.w);  // .long() then eq
+            }
+            for (int k = 4 * K4 + lane; k < K; k += 64) e += ((long long)dr[k] != (long long)tr[k]) ? 1 : 0;
+        } else {
+            for (int k = lane; k < K; k += 64) e += ((long long)dr[k] != (long long)tr[k]) ? 1 : 0;
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
         be += (unsigned long long)e;

@@ -29,6 +29,14 @@ def _as_f32(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+def _new_decisions(y: torch.Tensor, T: int) -> torch.Tensor:
+    """decoded_word = torch.zeros(y.shape) (va_detector.py:90); the zero fill is skipped when the kernel writes every
+    column (T == y.shape[1]) and there is at least one row."""
+    if T == y.shape[1] and y.shape[0] > 0 and T > 0:
+        return torch.empty(y.shape, dtype=torch.float32, device=y.device)
+    return torch.zeros(y.shape, dtype=torch.float32, device=y.device)
+
+
 def _check_T(T: int, y: torch.Tensor):
     if T > y.shape[1]:  # the reference indexes priors[:, i] for i < transmission_length (Q5)
         raise IndexError(f"index {y.shape[1]} is out of bounds for dimension 1 with size {y.shape[1]}")
@@ -102,7 +110,7 @@ class VADetector(nn.Module):
             raise RuntimeError(f"The size of tensor a ({B}) must match the size of tensor b ({W * (B // W)}) "
                                "at non-singleton dimension 0")
         _check_T(T, yc)
-        decoded_word = torch.zeros(yc.shape, dtype=torch.float32, device=yc.device)
+        decoded_word = _new_decisions(yc, T)
         with torch.cuda.device(yc.device):
             rc = _lib.load().mvn_va_decode_f32(_lib.ptr(yc), Ty, _lib.ptr(pri), W, _lib.ptr(decoded_word), Ty,
                                                None, B, T, self.n_states, _lib.current_stream(yc.device))
@@ -122,7 +130,7 @@ def _vnet_val(y: torch.Tensor, params, n_states: int, T: int, return_logits: boo
     if [tuple(t.shape) for t in w] != shapes:
         raise ValueError(f"ViterbiNet parameter shapes {[tuple(t.shape) for t in w]} != {shapes}")
     lib = _lib.load()
-    decoded_word = torch.zeros(yc.shape, dtype=torch.float32, device=yc.device)
+    decoded_word = _new_decisions(yc, T)
     logits = torch.empty((B, T, n_states), dtype=torch.float32, device=yc.device) if return_logits else None
     ws, ws_bytes = None, 0
     if logits is None:
