@@ -605,3 +605,37 @@ def test_va256_inplace_and_generic_paths(oracle, dev, monkeypatch, B, T):
         assert rc == 0
         assert np.array_equal(_np(dec), rdec), generic
         assert np.array_equal(_np(fm), rfm), generic
+
+
+def test_decode_is_graph_capturable(oracle, dev):
+    """include/mvn.h promises launches that never allocate or synchronise: capture decode + count in a HIP graph
+    (torch.cuda.CUDAGraph on a side stream), replay it on new inputs, compare with the oracle."""
+    S, B, T = 16, 64, 136
+    rng = np.random.RandomState(11)
+    w = _rand_weights(S, rng)
+    det = _vnet_with(w, S, T, dev)
+    y_static = torch.zeros(B, T, device=dev)
+    tx_static = torch.zeros(B, T, device=dev)
+    counters = torch.zeros(4, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        det(y_static, "val")  # warm-up outside capture (library load, LDS attribute calls)
+        det.val_count(y_static, tx_static, None, counters)
+    torch.cuda.current_stream().wait_stream(side)
+    counters.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        dec_static = det(y_static, "val")
+        det.val_count(y_static, tx_static, None, counters)
+    for trial in range(2):
+        y = rng.normal(0, 1.5, (B, T)).astype(np.float32)
+        tx = rng.randint(0, 2, (B, T)).astype(np.float32)
+        y_static.copy_(torch.tensor(y))
+        tx_static.copy_(torch.tensor(tx))
+        counters.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        rdec = oracle.vnet_decode(y, w)
+        assert np.array_equal(_np(dec_static), rdec)
+        assert counters.tolist() == oracle.count_errors(rdec, tx).tolist()
