@@ -213,10 +213,10 @@ def main():
             "ser_at_snr": ser,
             "fer_at_snr": fer,
             "fer_curve": fer_curve,
-            "roofline": {"kernel": "vnet16_fused_kernel<false,true> (ViterbiNet MLP on f32 MFMA 16x16x4 + in-place DPP trellis sweep)", "bound": "mfma",
+            "roofline": {"kernel": "vnet16_fused4_kernel<false> (ViterbiNet MLP on f32 MFMA 16x16x4 + 4x4x1, in-place DPP trellis sweep)", "bound": "mfma",
                          "achieved": mlp_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": mlp_tflops / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": measured_traffic("vnet16_fused_kernel<false, true>", B), "traffic_unit": "HBM bytes/launch",
+                         "traffic": measured_traffic("vnet16_fused4_kernel<false>", B), "traffic_unit": "HBM bytes/launch",
                          "algorithmic_hbm_bytes": 8.0 * B * T,
                          "ms_per_launch": ms_fused, "flop_per_symbol": FLOP_PER_SYMBOL},
             "roofline_acs_sweep": {"kernel": "sweep16_lds_kernel<COST> (mvn_acs_sweep_f32, LDS-DMA streamed costs)", "bound": "hbm",

@@ -22,6 +22,7 @@
 namespace {
 
 constexpr bool kFusedLdsDefault = true;
+constexpr bool kFused4Default = true;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -372,6 +373,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 }
 
 #include "vnet16_fused.inc"
+#include "vnet16_fused4.inc"
 #include "sweep16_rows.inc"
 #include "sweep16_lds.inc"
 #include "va256_inplace.inc"
@@ -477,6 +479,13 @@ bool unfused_forced() {
     return e && e[0] == '1';
 }
 
+// MVN_FUSED4=0/1 selects the 16-symbol-tile kernel (vnet16_fused.inc) or the 64-symbol super-tile kernel
+// (vnet16_fused4.inc).
+bool fused4_enabled() {
+    const char *e = getenv("MVN_FUSED4");
+    return e ? e[0] == '1' : kFused4Default;
+}
+
 // MVN_FUSED_LDSW=0/1 selects the register- or LDS-resident weight variant of the fused kernel.
 bool fused_lds_weights() {
     const char *e = getenv("MVN_FUSED_LDSW");
@@ -517,6 +526,16 @@ int launch_vnet16_fused(const float *y, int64_t y_ld, const float *W1, const flo
                         const float *W3, const float *b3, float *dec, int64_t dec_ld, float *logits_out,
                         float *final_metric, int64_t B, int T, const float *tx, int64_t tx_ld, int K,
                         const unsigned char *row_mask, unsigned long long *counters, hipStream_t st) {
+    if (fused4_enabled()) {  // 64-symbol super-tiles: units 48,49 on v_mfma_f32_4x4x1 instead of a padded row tile
+        const unsigned grid4 = (unsigned)((B + kFused4Waves - 1) / kFused4Waves);
+        if (logits_out)
+            hipLaunchKernelGGL((vnet16_fused4_kernel<true>), dim3(grid4), dim3(64 * kFused4Waves), 0, st, y, y_ld, W1, b1,
+                               W2, b2, W3, b3, dec, dec_ld, logits_out, final_metric, B, T, tx, tx_ld, K, row_mask, counters);
+        else
+            hipLaunchKernelGGL((vnet16_fused4_kernel<false>), dim3(grid4), dim3(64 * kFused4Waves), 0, st, y, y_ld, W1, b1,
+                               W2, b2, W3, b3, dec, dec_ld, logits_out, final_metric, B, T, tx, tx_ld, K, row_mask, counters);
+        return (int)hipGetLastError();
+    }
     const bool ldsw = fused_lds_weights();
     const int wpb = ldsw ? kFusedWavesLds : kFusedWaves;
     const unsigned grid = (unsigned)((B + wpb - 1) / wpb);
