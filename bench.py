@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=10000, help="blocks per GPU (BASELINE configs[1]: 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--skip-fused-count", action="store_true", help="(profiling) keep every fused-kernel dispatch decode-only")
+    ap.add_argument("--skip-fused-count", action="store_true", help="(profiling) keep every fused-kernel dispatch decode-only: no fused-count timing, no FER curve")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -165,14 +165,14 @@ def main():
     # FER@SNR / SER@SNR curve (the second half of BASELINE's metric), outside the timed region: fresh words per SNR
     # point on every rank, fused decode+count, one all-reduce of the int64[4] counters per point.
     fer_curve = []
-    for snr_db in (7.0, 8.0, 9.0, 10.0, 11.0, 12.0):  # plotter_main.py:117-122 sweeps 7..12 dB
+    for snr_db in (() if args.skip_fused_count else (7.0, 8.0, 9.0, 10.0, 11.0, 12.0)):  # plotter_main.py:117-122: 7..12 dB
         txs, ys = mvn.synthetic_words(B, T, L, snr_db, GAMMA, dev, seed=7860002 + 100 * int(snr_db) + rank)
         c = det.val_count(ys, txs)
         if world > 1:
             all_reduce(c)
         s_, f_ = mvn.rates_from_counters(c)
         fer_curve.append({"snr_db": snr_db, "ser": s_, "fer": f_, "frames": int(c[3].item())})
-    del txs, ys
+        del txs, ys
 
     out = None
     if rank == 0:
