@@ -640,3 +640,38 @@ def test_decode_is_graph_capturable(oracle, dev):
         rdec = oracle.vnet_decode(y, w)
         assert np.array_equal(_np(dec_static), rdec)
         assert counters.tolist() == oracle.count_errors(rdec, tx).tolist()
+
+
+def test_c_abi_demo(oracle, dev, tmp_path):
+    """examples/c_abi_demo.cpp binds include/mvn.h from plain C++ (no torch): same decisions and counters as the oracle."""
+    import os
+    import subprocess
+
+    import __graft_entry__ as ge
+
+    exe = ge.build_demo()
+    B, T, S, L = 37, 250, 16, 4
+    rng = np.random.RandomState(21)
+    w = _rand_weights(S, rng)
+    tx = rng.randint(0, 2, (B, T)).astype(np.float32)
+    y = rng.normal(0, 1.2, (B, T)).astype(np.float32)
+    h = mvn.estimate_channel(L, 0.2, "time_decay")
+    sym = 1 - 2 * ((np.arange(S)[:, None] >> np.arange(L)[::-1]) & 1)
+    pri = (sym @ h.T).T.astype(np.float32)
+    prob, res = tmp_path / "problem.bin", tmp_path / "result.bin"
+    with open(prob, "wb") as f:
+        np.array([B, T, S], np.int64).tofile(f)
+        for a in (y, pri, *w, tx):
+            np.ascontiguousarray(a, np.float32).tofile(f)
+    out = subprocess.run([exe, str(prob), str(res)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    raw = np.fromfile(res, np.uint8)
+    va = raw[: B * T * 4].view(np.float32).reshape(B, T)
+    vn = raw[B * T * 4: 2 * B * T * 4].view(np.float32).reshape(B, T)
+    counters = raw[2 * B * T * 4:].view(np.int64)
+    rva = oracle.va_decode(y, pri, want_final=False)
+    rvn = oracle.vnet_decode(y, w)
+    assert np.array_equal(va, rva) and np.array_equal(vn, rvn)
+    assert counters[:4].tolist() == oracle.count_errors(rva, tx).tolist()
+    assert counters[4:].tolist() == oracle.count_errors(rvn, tx).tolist()
+    assert "gfx950" in out.stdout
