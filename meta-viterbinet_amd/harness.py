@@ -132,19 +132,37 @@ def detect_by_word(detector: Callable, rx: torch.Tensor, snr: float, gamma: floa
 def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma: float, n_symbols: int,
                  subframes_in_frame: int, self_supervised: bool = False, online_trainer=None,
                  self_supervised_iterations: int = 200, ser_thresh: float = 0.02, pass_count: bool = False,
-                 verbose: bool = False) -> np.ndarray:
+                 verbose: bool = False, online_meta: bool = False, meta_detector=None, meta_lr: float = 0.1,
+                 MAML: bool = True, window_size: int = 1, meta_train_iterations: int = 20, meta_j_num: int = 10,
+                 meta_subframes: int = 5, meta_style_online_training: bool = False) -> np.ndarray:
     """Sequential per-block online evaluation: counterpart of Trainer.eval_by_word (trainer.py:267-354) with
-    buffer_empty=True and online_meta=False.  Everything but the control flow stays on the GPU:
+    buffer_empty=True and weights_init='last_frame'.  Everything but the control flow stays on the GPU:
         for every block k:  detect (B=1)  ->  data block: RS decode, ser, RS re-encode | pilot: encode the known word
-                            ->  if ser <= ser_thresh: keep (rx, label) where label = detected word if ser > 0 else the
-                                re-encoded word  ->  if self_supervised: online_trainer.online_training(label, rx)
+            ->  if ser <= ser_thresh: buffer (rx, label), label = detected word if ser > 0 else the re-encoded word
+            ->  if online_meta and k % meta_subframes == 0 (k >= meta_subframes, buffer > 2): restart from the saved
+                weights, meta_train_iterations x {meta_j_num random (support, query) pairs of consecutive buffered words ->
+                meta.meta_train_loop}, save the weights (:331-343)
+            ->  if self_supervised (and ser <= ser_thresh): online_trainer.online_training(last buffered pair) (:345-347);
+                meta_style_online_training=True first restores the saved weights and trains on the whole word
+                (metavnet_trainer.py:52-64), otherwise a 32-sample minibatch per iteration (vnet_trainer.py:49-60).
     tx [N, K] message bits, rx [N, K + 8*n_symbols] received words; block k is a pilot when k % subframes_in_frame == 0
     (trainer.py:100-102).  Returns ser_by_word [N] (0 for pilots), like the reference.
-    One host sync per block (the ser decides whether to train), as in the reference (trainer.py:305)."""
+    One host sync per block (the ser decides what happens next), as in the reference (trainer.py:305)."""
+    import copy
+
+    from .meta import copy_model, meta_train_loop
+
     N = tx.shape[0]
     ser_by_word = np.zeros(N)
-    if self_supervised and online_trainer is None:
-        raise ValueError("self_supervised=True needs an OnlineTrainer")
+    if (self_supervised or online_meta) and online_trainer is None:
+        raise ValueError("self_supervised / online_meta need an OnlineTrainer (it owns the Adam state)")
+    if online_meta and meta_detector is None:
+        raise ValueError("online_meta needs a META_VNETDetector")
+    saved_detector = copy.deepcopy(detector) if (online_meta or meta_style_online_training) else None  # :275
+    buffer_rx = torch.empty([0, rx.shape[1]], device=rx.device)
+    buffer_tx = torch.empty([0, rx.shape[1]], device=rx.device)
+    support_idx = torch.arange(-window_size - 1, -1, device=rx.device).long()  # :288
+    query_idx = -1 * torch.ones(1, device=rx.device).long()
     for count in range(N):
         transmitted_word, received_word = tx[count].reshape(1, -1), rx[count].reshape(1, -1)
         detected_word = detector(received_word, "val", snr, gamma, count) if pass_count else detector(received_word, "val", snr, gamma)
@@ -158,7 +176,20 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
             ser = 0.0
         if verbose:
             print(f"current: {count, ser}")
-        if ser <= ser_thresh and self_supervised:
-            label = detected_word if ser > 0 else encoded_word  # :321-324
-            online_trainer.online_training(label, received_word, iterations=self_supervised_iterations)  # :345-347
+        if ser <= ser_thresh:  # :319-329 (buffer_empty=True: the buffer only grows)
+            buffer_rx = torch.cat([buffer_rx, received_word])
+            buffer_tx = torch.cat([buffer_tx, detected_word.reshape(1, -1) if ser > 0 else encoded_word.reshape(1, -1)], dim=0)
+        if online_meta and count % meta_subframes == 0 and count >= meta_subframes and buffer_rx.shape[0] > 2:  # :331-343
+            copy_model(source_model=saved_detector, dest_model=detector)  # weights_init == 'last_frame' (:360-361)
+            for _ in range(meta_train_iterations):
+                j_hat_values = torch.unique(torch.randint(low=0, high=buffer_rx.shape[0] - 2, size=[meta_j_num])).to(rx.device)
+                for j_hat in j_hat_values:
+                    meta_train_loop(detector, meta_detector, online_trainer, buffer_rx, buffer_tx, j_hat + support_idx + 1,
+                                    j_hat + query_idx + 1, meta_lr, MAML)
+            copy_model(source_model=detector, dest_model=saved_detector)
+        if self_supervised and ser <= ser_thresh:  # :345-347
+            if meta_style_online_training:
+                copy_model(source_model=saved_detector, dest_model=detector)  # metavnet_trainer.py:59
+            online_trainer.online_training(buffer_tx[-1].reshape(1, -1), buffer_rx[-1].reshape(1, -1),
+                                           iterations=self_supervised_iterations, full_word=meta_style_online_training)
     return ser_by_word

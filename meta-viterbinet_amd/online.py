@@ -24,6 +24,25 @@ class OnlineTrainer:
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step = 0
 
+    @torch.no_grad()
+    def adam_step(self, grads):
+        """One torch.optim.Adam step (amsgrad off, no weight decay) on the detector from a list of gradients, using and
+        updating the SAME exp_avg / exp_avg_sq / step as the online-training kernel (the reference has one optimizer for
+        run_train_loop and meta_train_loop, trainer.py:163-173,452,503)."""
+        self.step += 1
+        b1, b2 = self.betas
+        bc1, bc2 = 1.0 - b1 ** self.step, 1.0 - b2 ** self.step
+        step_size = self.lr / bc1
+        off = 0
+        for p, g in zip(self.params, grads):
+            n = p.numel()
+            m, v = self.exp_avg[off:off + n].view_as(p), self.exp_avg_sq[off:off + n].view_as(p)
+            m.mul_(b1).add_(g, alpha=1.0 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+            denom = (v.sqrt() / (bc2 ** 0.5)).add_(self.eps)
+            p.data.addcdiv_(m, denom, value=-step_size)
+            off += n
+
     def select_batches(self, T: int, iterations: int) -> torch.Tensor:
         """`iterations` minibatches drawn like select_batch (trainer.py:542): torch.multinomial with weights
         arange(T) (sample 0 is never drawn), without replacement, all iterations in one call."""
@@ -38,6 +57,7 @@ class OnlineTrainer:
         p = self.params
         dev = p[0].device
         _lib.require_gpu_tensor(rx, "rx")
+        _lib.require_gpu_tensor(p[0], "detector parameters")
         y = rx.detach().to(torch.float32).reshape(-1).contiguous()
         T = y.numel()
         labels = calculate_states(self.memory_length, tx.detach().to(dev).reshape(1, -1)).to(torch.int32).contiguous()

@@ -418,6 +418,43 @@ def g10_online_training():
     save("g10_online_training", **out)
 
 
+# ----------------------------------------------------------------------------- G11
+def g11_meta_train_loop():
+    """Trainer.meta_train_loop (trainer.py:425-453) on a few buffered words: MAML and first-order variants."""
+    from python_code.trainers.META_VNET.metavnet_trainer import METAVNETTrainer
+    from python_code.ecc.rs_main import encode
+
+    out = {}
+    for maml in (True, False):
+        torch.manual_seed(5)
+        torch.set_num_threads(1)
+        tr = METAVNETTrainer(use_ecc=True, n_symbols=2, memory_length=4, val_block_length=120, val_frames=1,
+                             subframes_in_frame=6, train_block_length=120, train_frames=1, train_minibatch_num=1,
+                             channel_coefficients="time_decay", fading_in_channel=True, fading_in_decoder=False,
+                             fading_taps_type=2, noisy_est_var=0, val_SNR_start=10, val_SNR_end=10, gamma=0.2,
+                             weights_dir=TMP, self_supervised=True, online_meta=True, MAML=maml, meta_lr=0.1,
+                             window_size=1, eval_mode="by_word", noise_seed=3450002, word_seed=7860002)
+        tr.deep_learning_setup()
+        tx_msg, rx = tr.channel_dataset["val"].__getitem__(snr_list=[10], gamma=0.2)
+        tx = torch.cat([torch.Tensor(encode(w.int().numpy(), 2).reshape(1, -1)) for w in tx_msg], dim=0)
+        w0 = export_weights(tr.detector)
+        losses = []
+        pairs = [(0, 1), (2, 3), (4, 5), (1, 2)]
+        for (sup, qry) in pairs:
+            losses.append(float(tr.meta_train_loop(rx, tx, torch.tensor([sup]), torch.tensor([qry]))))
+        tag = "maml" if maml else "fo"
+        out[f"{tag}_loss"] = np.array(losses)
+        for i, w in enumerate(export_weights(tr.detector)):
+            out[f"{tag}_w1_{i}"] = w
+        for i, w in enumerate(w0):
+            out[f"{tag}_w0_{i}"] = w
+        out["tx"], out["rx"] = tx.numpy().astype(np.uint8), rx.numpy()
+        out["pairs"] = np.array(pairs, np.int64)
+        out["lr"], out["meta_lr"] = np.array(tr.lr), np.array(tr.meta_lr)
+        print("meta_train_loop", tag, losses)
+    save("g11_meta_train_loop", **out)
+
+
 # ----------------------------------------------------------------------------- G8
 def g8_rs():
     """RS(n,k) KATs through the reference's own encode/decode (rs_main.py:9-37), incl. patterns beyond the
@@ -467,6 +504,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g8":
         g8_rs()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g11":
+        g11_meta_train_loop()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g10":
         g10_online_training()
         sys.exit(0)
@@ -492,6 +532,7 @@ if __name__ == "__main__":
     with contextlib.redirect_stdout(buf):
         g9_by_word_va()
         g10_online_training()
+        g11_meta_train_loop()
         g7_by_word(trained4)
     print("\n".join(l for l in buf.getvalue().splitlines() if l.startswith(("time_decay", "cost2100", "wrote", "Final"))))
     print("torch", torch.__version__, "numpy", np.__version__)

@@ -675,3 +675,29 @@ def test_c_abi_demo(oracle, dev, tmp_path):
     assert counters[:4].tolist() == oracle.count_errors(rva, tx).tolist()
     assert counters[4:].tolist() == oracle.count_errors(rvn, tx).tolist()
     assert "gfx950" in out.stdout
+
+
+def test_eval_by_word_online_meta_runs(golden, dev):
+    """BASELINE configs[4] flow: Meta-ViterbiNet online evaluation = detect + RS + buffer + MAML meta-steps every
+    meta_subframes blocks (torch autograd through META_VNETDetector) + self-supervised training restarted from the saved
+    weights on the whole word (metavnet_trainer.py:52-64, HIP online-training kernel).  Statistical sanity only."""
+    g7 = golden("g7_by_word")
+    w = [g7[f"w{i}"] for i in range(6)]
+    N, K, nsym, L, snr = 60, 120, 2, 4, 10.0
+    gen = torch.Generator(device=dev).manual_seed(9)
+    msg = torch.randint(0, 2, (N, K), generator=gen, device=dev).float()
+    cw = mvn.rs_encode(msg, nsym)
+    h = np.concatenate([mvn.estimate_channel(L, 0.2, "time_decay", fading=True, index=i, fading_taps_type=2) for i in range(N)])
+    y = mvn.transmit(cw, h, snr, L, torch.randn(N, K + 8 * nsym, generator=gen, device=dev))
+    det = _vnet_with(w, 16, K + 8 * nsym, dev)
+    meta = mvn.META_VNETDetector(16, {"train": K + 8 * nsym, "val": K + 8 * nsym})
+    tr = mvn.OnlineTrainer(det, L)
+    torch.manual_seed(1)
+    ser = mvn.eval_by_word(det, msg, y, snr, 0.2, nsym, 25, self_supervised=True, online_trainer=tr,
+                           self_supervised_iterations=20, online_meta=True, meta_detector=meta, meta_train_iterations=2,
+                           meta_j_num=3, meta_subframes=5, meta_style_online_training=True)
+    assert ser.shape == (N,) and np.all(ser[::25] == 0) and np.all(np.isfinite(ser))
+    assert tr.step > 20 * 20  # self-supervised steps + meta steps were taken
+    assert float(ser.mean()) < 0.2
+    for p in det.parameters():
+        assert torch.isfinite(p).all()

@@ -117,3 +117,26 @@ def test_rates_from_counters():
     assert mvn.rates_from_counters(torch.tensor([3, 100, 1, 4])) == (0.03, 0.25)
     ser, fer = mvn.rates_from_counters(torch.tensor([0, 0, 0, 0]))
     assert np.isnan(ser) and np.isnan(fer)
+
+
+@pytest.mark.parametrize("tag,maml", [("maml", True), ("fo", False)])
+def test_meta_train_loop_golden(golden, tag, maml):
+    """G11: four Trainer.meta_train_loop steps of the reference (second-order MAML and first-order), CPU torch.
+    Same autograd graph; the Adam update runs through OnlineTrainer.adam_step.  Tolerance 1e-6 abs (op order of Adam)."""
+    g = golden("g11_meta_train_loop")
+    torch.set_num_threads(1)
+    det = mvn.VNETDetector(16, {"train": 136, "val": 136}).to("cpu")
+    with torch.no_grad():
+        for i, p in enumerate(det.parameters()):
+            p.copy_(torch.tensor(g[f"{tag}_w0_{i}"]))
+    meta = mvn.META_VNETDetector(16, {"train": 136, "val": 136})
+    tr = mvn.OnlineTrainer(det, 4, lr=float(g["lr"]))
+    tx, rx = torch.tensor(g["tx"].astype(np.float32)), torch.tensor(g["rx"])
+    losses = []
+    for sup, qry in g["pairs"]:
+        losses.append(float(mvn.meta_train_loop(det, meta, tr, rx, tx, torch.tensor([int(sup)]), torch.tensor([int(qry)]),
+                                                float(g["meta_lr"]), maml)))
+    assert np.allclose(losses, g[f"{tag}_loss"], rtol=1e-6)
+    for i, p in enumerate(det.parameters()):
+        assert np.allclose(p.detach().numpy(), g[f"{tag}_w1_{i}"], rtol=0, atol=1e-6), i
+    assert tr.step == 4
