@@ -88,6 +88,22 @@ def cpu_baseline(weights_np, seed):
             "sample": f"oracle.vnet_decode on {blocks} blocks x {T} symbols (same generator/weights), {dt:.1f} s"}
 
 
+def cpu_baseline_torch_path(weights_np, seed):
+    """The reference's own op sequence on torch-CPU (oracle/torch_path.py: per stage the same ATen calls as
+    trellis_utils.py:16-30 inside vnet_detector.py:53-59), all host cores, bounded sample."""
+    from oracle import torch_path
+
+    blocks = 1000
+    _, y = mvn.synthetic_words(blocks, T, L, SNR_DB, GAMMA, "cpu", seed=seed)
+    torch_path.vnet_val(y[:50], weights_np)
+    t0 = time.perf_counter()
+    torch_path.vnet_val(y, weights_np)
+    dt = time.perf_counter() - t0
+    return {"value": blocks * T / dt, "unit": "symbols/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/torch_path.vnet_val (op-for-op PyTorch-CPU restatement of the reference's forward('val')) on "
+                      f"{blocks} blocks x {T} symbols, {dt:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,6 +249,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline([w.cpu().numpy() for w in weights], 3450002)
+            out["cpu_baseline_torch_path"] = cpu_baseline_torch_path([w.cpu().numpy() for w in weights], 3450002)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -198,3 +198,22 @@ def test_by_word_va_rs_end_to_end(golden, oracle, coef):
     pilots = np.setdiff1d(np.arange(300), data)
     assert np.all(ref[pilots] == 0)
     assert np.count_nonzero(ref) > 0
+
+
+# ---- the torch-CPU op-for-op restatement used as the "reference's CPU/PyTorch path" timing proxy -----------------
+def test_torch_path_matches_reference(golden):
+    import torch
+
+    from oracle import torch_path
+
+    torch.set_num_threads(1)
+    g = golden("g2_va")
+    for name in ("L4_static", "L4_fading1", "L8_static"):
+        pri = torch.tensor(np.ascontiguousarray(g[f"{name}_state_priors"].T))
+        dec = torch_path.va_val(torch.tensor(g[f"{name}_rx"]), pri)
+        assert np.array_equal(dec.numpy(), g[f"{name}_decoded"].astype(np.float32))
+    g = golden("g3_vnet")
+    for name in ("S16_trained_exact", "S4_trained_exact"):
+        w = [g[f"{name}_w{i}"] for i in range(6)]
+        dec = torch_path.vnet_val(torch.tensor(g[f"{name}_y"]), w)
+        assert np.array_equal(dec.numpy(), g[f"{name}_decoded"].astype(np.float32))
