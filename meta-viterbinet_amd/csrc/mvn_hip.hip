@@ -384,7 +384,8 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 // metrics.py:7-17 as integer counters.  One wave per row, block-level reduction, one atomic
 // per workgroup per counter.
 // -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void count_errors_kernel(const float *__restrict__ dec, int64_t dec_ld,
+constexpr int kCountWaves = 16;
+__global__ __launch_bounds__(64 * kCountWaves) void count_errors_kernel(const float *__restrict__ dec, int64_t dec_ld,
                                                            const float *__restrict__ tx, int64_t tx_ld,
                                                            const int64_t *__restrict__ rows, int64_t n_rows,
                                                            int K, unsigned long long *counters) {
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(256) void count_errors_kernel(const float *__restri
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     unsigned long long be = 0, fe = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n_rows; i += (int64_t)gridDim.x * 4) {
+    for (int64_t i = (int64_t)blockIdx.x * kCountWaves + wave; i < n_rows; i += (int64_t)gridDim.x * kCountWaves) {
         const int64_t r = rows ? rows[i] : i;
         int e = 0;
         const float *dr = dec + r * dec_ld, *tr = tx + r * tx_ld;
@@ -522,6 +523,26 @@ unsigned fused_dynamic_lds_pad(int64_t B) {
     return need > 0 ? (unsigned)need : 0;
 }
 
+// counters[1] += K * (#counted rows), counters[3] += #counted rows  (rows with mask != 0, or all B when mask is NULL)
+__global__ __launch_bounds__(1024) void count_totals_kernel(const unsigned char *__restrict__ row_mask, int64_t B, int K,
+                                                            unsigned long long *counters) {
+    __shared__ unsigned long long s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    unsigned long long n = 0;
+    if (row_mask) {
+        for (int64_t i = threadIdx.x; i < B; i += blockDim.x) n += row_mask[i] != 0;
+        if (n) atomicAdd(&s_n, n);
+    } else if (threadIdx.x == 0) {
+        s_n = (unsigned long long)B;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&counters[1], s_n * (unsigned long long)K);
+        atomicAdd(&counters[3], s_n);
+    }
+}
+
 int launch_vnet16_fused(const float *y, int64_t y_ld, const float *W1, const float *b1, const float *W2, const float *b2,
                         const float *W3, const float *b3, float *dec, int64_t dec_ld, float *logits_out,
                         float *final_metric, int64_t B, int T, const float *tx, int64_t tx_ld, int K,
@@ -534,6 +555,7 @@ int launch_vnet16_fused(const float *y, int64_t y_ld, const float *W1, const flo
         else
             hipLaunchKernelGGL((vnet16_fused4_kernel<false>), dim3(grid4), dim3(64 * kFused4Waves), 0, st, y, y_ld, W1, b1,
                                W2, b2, W3, b3, dec, dec_ld, logits_out, final_metric, B, T, tx, tx_ld, K, row_mask, counters);
+        if (tx) hipLaunchKernelGGL(count_totals_kernel, dim3(1), dim3(1024), 0, st, row_mask, B, K, counters);
         return (int)hipGetLastError();
     }
     const bool ldsw = fused_lds_weights();
@@ -799,9 +821,10 @@ int mvn_count_errors(const float *dec, int64_t dec_ld, const float *tx, int64_t 
     if (!counters) return MVN_E_NULL;
     if (n_rows == 0 || K == 0) return MVN_OK;
     if (!dec || !tx) return MVN_E_NULL;
-    int64_t want = (n_rows + 3) / 4;
-    unsigned grid = (unsigned)(want < 2048 ? want : 2048);
-    hipLaunchKernelGGL(count_errors_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dec, dec_ld, tx,
+    // few, large workgroups: the two global atomics per workgroup (all on the same two words) are the serial part
+    int64_t want = (n_rows + kCountWaves - 1) / kCountWaves;
+    unsigned grid = (unsigned)(want < 512 ? want : 512);
+    hipLaunchKernelGGL(count_errors_kernel, dim3(grid), dim3(64 * kCountWaves), 0, (hipStream_t)stream, dec, dec_ld, tx,
                        tx_ld, rows, n_rows, K, (unsigned long long *)counters);
     return (int)hipGetLastError();
 }
