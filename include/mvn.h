@@ -16,7 +16,10 @@
  *   - decisions are written as fp32 {0.,1.} like the reference's decoded_word
  *     (va_detector.py:90-93); columns >= T of `dec` are not touched (caller zero-fills).
  *   - arithmetic is IEEE fp32 with one rounding per reference operation; results are
- *     bit-identical to oracle/mvn_oracle.c for finite inputs (NaN inputs: unspecified).
+ *     bit-identical to oracle/mvn_oracle.c for finite inputs, for +-inf, and for NaN samples in y
+ *     (all branch costs of that symbol become NaN, as in the reference); a NaN in only SOME of a
+ *     symbol's branch costs (e.g. NaN weights or priors) is unspecified: torch.min propagates it,
+ *     v_min_f32 does not.
  */
 #ifndef MVN_H_
 #define MVN_H_

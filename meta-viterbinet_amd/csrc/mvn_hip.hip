@@ -40,6 +40,7 @@ constexpr int kK3Steps = (kH2 + 3) / 4;  // 13 MFMA k-steps for layer 3 (k 50,51
 // -------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoid_from_neg(float d) {
     float dc = fminf(fmaxf(d, -128.0f), 128.0f);
+    dc = d != d ? d : dc;  // NaN in -> NaN out, like the reference (the clamp alone would swallow it)
     float t = dc * 1.442695040888963407359924681001892137426645954152985934135449406931f;
     float qf = __builtin_rintf(t);
     int q = (int)qf;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(64 * kSweepWaves) void sweep_kernel(
                 int bi = sl;
 #pragma unroll
                 for (int r = 1; r < R; ++r)
-                    if (m[r] < bv) {
+                    if (m[r] < bv || (m[r] != m[r] && bv == bv)) {  // strict: lower index wins ties; first NaN wins
                         bv = m[r];
                         bi = sl + LPB * r;
                     }
@@ -148,7 +149,9 @@ __global__ __launch_bounds__(64 * kSweepWaves) void sweep_kernel(
                 for (int off = 1; off < LPB; off <<= 1) {
                     float ov = __shfl_xor(bv, off);
                     int oi = __shfl_xor(bi, off);
-                    bool take = (ov < bv) || (ov == bv && oi < bi);
+                    // torch.argmin order: NaN sorts before everything, ties (and NaN vs NaN) go to the lower index
+                    const bool onan = ov != ov, bnan = bv != bv;
+                    bool take = onan ? (!bnan || oi < bi) : (!bnan && ((ov < bv) || (ov == bv && oi < bi)));
                     bv = take ? ov : bv;
                     bi = take ? oi : bi;
                 }
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(64 * kMlpWaves, 2) void mlp_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float z = acc[tau][r] + b2v[tau][r];
-                u[r] = __float_as_uint(z > 0.0f ? z : 0.0f);
+                u[r] = __float_as_uint(z < 0.0f ? 0.0f : z)  /* relu; NaN propagates like torch's */;
             }
             u32x2 p;
             p = __builtin_amdgcn_permlane32_swap(u[0], u[2], false, false);

@@ -701,3 +701,56 @@ def test_eval_by_word_online_meta_runs(golden, dev):
     assert float(ser.mean()) < 0.2
     for p in det.parameters():
         assert torch.isfinite(p).all()
+
+
+def test_nonfinite_samples_like_reference(oracle, dev):
+    """NaN / +-inf received samples: the reference turns every branch cost of that symbol into NaN (ViterbiNet: the MLP
+    propagates it; VA: (NaN - prior)^2), after which torch.min/argmin leave all metrics NaN and every later decision 0.
+    The kernels reproduce that (oracle = torch semantics)."""
+    S, B, T = 16, 6, 70
+    rng = np.random.RandomState(4)
+    w = _rand_weights(S, rng)
+    y = rng.normal(0, 1.5, (B, T)).astype(np.float32)
+    y[1, 20] = np.nan
+    y[2, 0] = np.nan
+    y[3, 33] = np.inf
+    y[4, 50] = -np.inf
+    y[5, 69] = np.nan
+    pri = rng.normal(0, 1, (1, S)).astype(np.float32)
+    yt = torch.tensor(y, device=dev)
+    with np.errstate(all="ignore"):
+        rdec = oracle.vnet_decode(y, w)
+        vdec = oracle.va_decode(y, pri, want_final=False)
+    det = _vnet_with(w, S, T, dev)
+    assert np.array_equal(_np(det(yt, "val")), rdec)
+    assert np.all(rdec[1, 22:] == 0) and np.all(rdec[2, 2:] == 0)  # everything after a NaN sample decodes to 0
+    pt = torch.tensor(pri, device=dev)
+    d2 = torch.zeros_like(yt)
+    rc = mvn._lib.load().mvn_va_decode_f32(mvn._lib.ptr(yt), T, mvn._lib.ptr(pt), 1, mvn._lib.ptr(d2), T, None, B, T, S,
+                                           mvn._lib.current_stream(dev))
+    assert rc == 0 and np.array_equal(_np(d2), vdec)
+
+
+@pytest.mark.parametrize("S", [4, 16, 64, 256])
+def test_nonfinite_samples_generic_paths(oracle, dev, monkeypatch, S):
+    """Same property on the generic kernels (two-kernel ViterbiNet route, LDS-exchange sweep) for several S."""
+    monkeypatch.setenv("MVN_GENERIC_SWEEP", "1")
+    monkeypatch.setenv("MVN_UNFUSED", "1")
+    B, T = 5, 40
+    rng = np.random.RandomState(S)
+    w = _rand_weights(S, rng)
+    y = rng.normal(0, 1.5, (B, T)).astype(np.float32)
+    y[1, 7] = np.nan
+    y[2, 0] = np.nan
+    y[3, 20] = np.inf
+    pri = rng.normal(0, 1, (1, S)).astype(np.float32)
+    yt = torch.tensor(y, device=dev)
+    with np.errstate(all="ignore"):
+        rdec = oracle.vnet_decode(y, w)
+        vdec = oracle.va_decode(y, pri, want_final=False)
+    assert np.array_equal(_np(_vnet_with(w, S, T, dev)(yt, "val")), rdec)
+    pt = torch.tensor(pri, device=dev)
+    d2 = torch.zeros_like(yt)
+    rc = mvn._lib.load().mvn_va_decode_f32(mvn._lib.ptr(yt), T, mvn._lib.ptr(pt), 1, mvn._lib.ptr(d2), T, None, B, T, S,
+                                           mvn._lib.current_stream(dev))
+    assert rc == 0 and np.array_equal(_np(d2), vdec)
