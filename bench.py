@@ -10,6 +10,7 @@ resident in HBM).  Blocks are independent: every rank owns its own 10 000 blocks
 collective is one all-reduce of the int64[4] error counters at the end.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -39,15 +40,17 @@ def golden_weights(device):
     return [torch.tensor(g[f"w{i}"], device=device) for i in range(6)]
 
 
-def measured_traffic(kernel, B):
+def measured_traffic(kernel, B, prefix=False):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, collected with
     tools/pmc_traffic.sh on this same command); None when the workload differs from the profiled one."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         w = t["workload"]
         if (w["blocks"], w["block_length"], w["n_states"]) == (B, T, S):
+            if prefix:  # template arguments vary (e.g. <0, true>): match on the kernel's base name
+                kernel = next(k for k in t if k.startswith(kernel + "<"))
             return t[kernel]["bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, StopIteration):
         pass
     return None
 
@@ -210,6 +213,9 @@ def main():
         del cost
         mlp_tflops = FLOP_PER_SYMBOL * B * T / (ms_fused * 1e-3) / 1e12
         acs_gbps = ACS_BYTES_PER_SYMBOL * B * T / (ms_acs * 1e-3) / 1e9
+        name_buf = ctypes.create_string_buffer(64)
+        assert lib.mvn_acs_sweep_kernel_name(B, T, S, name_buf, 64) == 0
+        acs_kernel = name_buf.value.decode()
         out = {
             "metric": "decoded symbols/sec, ViterbiNet L=4 ISI (16 states)",
             "value": total_symbols / elapsed,
@@ -236,10 +242,10 @@ def main():
                          "traffic": measured_traffic("vnet16_fused4_kernel<false>", B), "traffic_unit": "HBM bytes/launch",
                          "algorithmic_hbm_bytes": 8.0 * B * T,
                          "ms_per_launch": ms_fused, "flop_per_symbol": FLOP_PER_SYMBOL},
-            "roofline_acs_sweep": {"kernel": "sweep16_lds_kernel<COST> (mvn_acs_sweep_f32, LDS-DMA streamed costs)", "bound": "hbm",
+            "roofline_acs_sweep": {"kernel": acs_kernel + "<COST> (mvn_acs_sweep_f32, LDS-DMA streamed costs)", "bound": "hbm",
                                    "achieved": acs_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                    "frac": acs_gbps / PEAK_HBM_GBPS,
-                                   "traffic": measured_traffic("sweep16_lds_kernel<0>", B),
+                                   "traffic": measured_traffic(acs_kernel, B, prefix=True),
                                    "traffic_unit": "HBM bytes/launch", "algorithmic_hbm_bytes": ACS_BYTES_PER_SYMBOL * B * T,
                                    "ms_per_launch": ms_acs,
                                    "bytes_per_symbol": ACS_BYTES_PER_SYMBOL},

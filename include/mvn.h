@@ -71,6 +71,13 @@ int mvn_acs_sweep_f32(const float *cost, float *dec, int64_t dec_ld, float *fina
                       int64_t B, int32_t T, int32_t S, mvn_stream_t stream);
 
 /*
+ * Introspection for profiling tools (no reference counterpart): name of the device kernel mvn_acs_sweep_f32
+ * launches for this shape on the current device, honouring the MVN_* environment switches.  Host pointer;
+ * returns 0, or MVN_E_STATES / MVN_E_NULL.
+ */
+int mvn_acs_sweep_kernel_name(int64_t B, int32_t T, int32_t S, char *name, int32_t name_len);
+
+/*
  * VADetector.forward(y,'val'), python_code/detectors/VA/va_detector.py:73-98, given the
  * state priors of compute_state_priors (:42-50) as a [Bp,S] table (row b uses b % Bp, the
  * `.repeat` of :64-65): branch costs (y-prior)^2/2 - log(sqrt(2*pi)) (:64-68) are computed in

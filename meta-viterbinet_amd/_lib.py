@@ -23,6 +23,7 @@ SIGNATURES = {
                                        ctypes.c_char_p, ctypes.c_int]),
     "mvn_acs_block_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "mvn_acs_sweep_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
+    "mvn_acs_sweep_kernel_name": (ctypes.c_int, [_i64, _i32, _i32, ctypes.c_char_p, _i32]),
     "mvn_va_decode_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
     "mvn_vnet_logits_f32": (ctypes.c_int, [_vp] * 8 + [_i64, _i32, _vp]),
     "mvn_vnet_workspace_bytes": (ctypes.c_size_t, [_i64, _i32, _i32]),

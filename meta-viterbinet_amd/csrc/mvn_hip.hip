@@ -379,6 +379,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 #include "vnet16_fused4.inc"
 #include "sweep16_rows.inc"
 #include "sweep16_lds.inc"
+#include "sweep16_quad.inc"
 #include "va256_inplace.inc"
 #include "rs_codec.inc"
 #include "online_train.inc"
@@ -583,13 +584,21 @@ bool generic_sweep_forced() {
     return e && e[0] == '1';
 }
 
+// which cost-streaming kernel serves a 16-state sweep: 'q'uad, 'l'ds or 'r'ows
+char sweep16_variant(int64_t B) {
+    const char *e = getenv("MVN_SWEEP16");  // "rows" | "lds" | "quad" pins a variant (A/B, tests); default by size
+    if (e && (e[0] == 'q' || e[0] == 'l' || e[0] == 'r')) return e[0];
+    return sweep16_quad_preferred(B) ? 'q' : 'l';
+}
+
 template <int MODE>
 int dispatch_sweep(const float *src, int64_t src_ld, const float *priors, int64_t Bp, float *dec, int64_t dec_ld,
                    float *final_metric, int64_t B, int T, int S, hipStream_t st) {
     if (S == 16 && !generic_sweep_forced()) {
         if constexpr (MODE != MODE_VA) {  // materialised costs: stream them through LDS in 1-KB pieces
-            const char *e = getenv("MVN_SWEEP16");  // "rows" = register-prefetch variant (A/B, tests)
-            if (!(e && e[0] == 'r')) return launch_sweep16_lds<MODE>(src, dec, dec_ld, final_metric, B, T, st);
+            const char v = sweep16_variant(B);
+            if (v == 'q') return launch_sweep16_quad<MODE>(src, dec, dec_ld, final_metric, B, T, st);
+            if (v != 'r') return launch_sweep16_lds<MODE>(src, dec, dec_ld, final_metric, B, T, st);
         }
         return launch_sweep16_rows<MODE>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
     }
@@ -665,6 +674,19 @@ int mvn_acs_sweep_f32(const float *cost, float *dec, int64_t dec_ld, float *fina
     if (!cost || !dec) return MVN_E_NULL;
     return dispatch_sweep<MODE_COST>(cost, 0, nullptr, 1, dec, dec_ld, final_metric, B, T, S,
                                    (hipStream_t)stream);
+}
+
+int mvn_acs_sweep_kernel_name(int64_t B, int32_t T, int32_t S, char *name, int32_t name_len) {
+    (void)T;
+    if (!valid_states(S)) return MVN_E_STATES;
+    if (!name || name_len < 1) return MVN_E_NULL;
+    const char *k = "sweep_kernel";
+    if (S == 16 && !generic_sweep_forced()) {
+        const char v = sweep16_variant(B);
+        k = v == 'q' ? "sweep16_quad_kernel" : v == 'l' ? "sweep16_lds_kernel" : "sweep16_rows_kernel";
+    }
+    snprintf(name, (size_t)name_len, "%s", k);
+    return MVN_OK;
 }
 
 int mvn_va_decode_f32(const float *y, int64_t y_ld, const float *state_priors, int64_t Bp, float *dec,

@@ -250,7 +250,7 @@ def test_sweep16_rows_and_generic_paths(oracle, dev, monkeypatch, B, T):
     rdec, rfm = oracle.acs_sweep(cost)
     vdec, vfm = oracle.va_decode(y, pri)
     ct, yt, pt = torch.tensor(cost, device=dev), torch.tensor(y, device=dev), torch.tensor(pri, device=dev)
-    for generic, variant in (("0", "lds"), ("0", "rows"), ("1", "lds")):
+    for generic, variant in (("0", "lds"), ("0", "rows"), ("0", "quad"), ("1", "lds")):
         monkeypatch.setenv("MVN_GENERIC_SWEEP", generic)
         monkeypatch.setenv("MVN_SWEEP16", variant)  # LDS-DMA streaming vs register-prefetch row sweep
         dec, fm = mvn.acs_sweep(ct, return_final=True)
@@ -261,6 +261,37 @@ def test_sweep16_rows_and_generic_paths(oracle, dev, monkeypatch, B, T):
                                                mvn._lib.ptr(f2), B, T, S, mvn._lib.current_stream(dev))
         assert rc == 0
         assert np.array_equal(_np(d2), vdec) and np.array_equal(_np(f2), vfm), generic
+
+
+def test_sweep16_quad_variant(oracle, dev, monkeypatch):
+    """16-blocks-per-wave sweep: picked by default when its last round of waves is well filled (7 500 blocks = 469
+    of 768 waves); both store paths (16-B aligned rows / arbitrary row stride), partial last chunk, partial last wave,
+    and the -logit mode of the two-kernel ViterbiNet route."""
+    import ctypes
+    S, B, T = 16, 7500, 50
+    lib = mvn._lib.load()
+    buf = ctypes.create_string_buffer(64)
+    assert lib.mvn_acs_sweep_kernel_name(B, T, S, buf, 64) == 0 and buf.value == b"sweep16_quad_kernel"
+    assert lib.mvn_acs_sweep_kernel_name(100, T, S, buf, 64) == 0 and buf.value == b"sweep16_lds_kernel"
+    assert lib.mvn_acs_sweep_kernel_name(100, T, 4, buf, 64) == 0 and buf.value == b"sweep_kernel"
+    rng = np.random.RandomState(77)
+    cost = rng.normal(0, 2, (B, T, S)).astype(np.float32)
+    cost[:40] = np.round(cost[:40])  # exact ties
+    rdec, rfm = oracle.acs_sweep(cost)
+    ct = torch.tensor(cost, device=dev)
+    st = mvn._lib.current_stream(dev)
+    for ld in (T + 2, T + 1):  # 52: float4 stores; 51: scalar stores
+        dec = torch.full((B, ld), 7.0, device=dev)
+        fm = torch.empty(B, S, device=dev)
+        assert lib.mvn_acs_sweep_f32(mvn._lib.ptr(ct), mvn._lib.ptr(dec), ld, mvn._lib.ptr(fm), B, T, S, st) == 0
+        assert np.array_equal(_np(dec[:, :T]), rdec) and np.array_equal(_np(fm), rfm), ld
+        assert bool((dec[:, T:] == 7.0).all())  # nothing written past T
+    monkeypatch.setenv("MVN_SWEEP16", "quad")
+    monkeypatch.setenv("MVN_UNFUSED", "1")
+    w = _rand_weights(S, rng)
+    y = rng.normal(0, 1.5, (37, 70)).astype(np.float32)
+    got = _vnet_with(w, S, 70, dev)(torch.tensor(y, device=dev), "val")
+    assert np.array_equal(_np(got), oracle.vnet_decode(y, w))
 
 
 def test_vnet_workspace_slicing(oracle, dev, monkeypatch):
