@@ -380,6 +380,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 #include "sweep16_rows.inc"
 #include "sweep16_lds.inc"
 #include "sweep16_quad.inc"
+#include "va16_quad.inc"
 #include "va256_inplace.inc"
 #include "rs_codec.inc"
 #include "online_train.inc"
@@ -599,6 +600,11 @@ int dispatch_sweep(const float *src, int64_t src_ld, const float *priors, int64_
             const char v = sweep16_variant(B);
             if (v == 'q') return launch_sweep16_quad<MODE>(src, dec, dec_ld, final_metric, B, T, st);
             if (v != 'r') return launch_sweep16_lds<MODE>(src, dec, dec_ld, final_metric, B, T, st);
+        }
+        if constexpr (MODE == MODE_VA) {  // MVN_VA16 = "rows" | "quad" pins a variant (A/B, tests); default by size
+            const char *e = getenv("MVN_VA16");
+            if (e ? e[0] == 'q' : B >= kVaQuadMinBlocks)
+                return launch_va16_quad(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
         }
         return launch_sweep16_rows<MODE>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
     }

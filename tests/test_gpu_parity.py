@@ -253,6 +253,7 @@ def test_sweep16_rows_and_generic_paths(oracle, dev, monkeypatch, B, T):
     for generic, variant in (("0", "lds"), ("0", "rows"), ("0", "quad"), ("1", "lds")):
         monkeypatch.setenv("MVN_GENERIC_SWEEP", generic)
         monkeypatch.setenv("MVN_SWEEP16", variant)  # LDS-DMA streaming vs register-prefetch row sweep
+        monkeypatch.setenv("MVN_VA16", "quad" if variant == "quad" else "rows")  # 16 / 4 blocks per wave
         dec, fm = mvn.acs_sweep(ct, return_final=True)
         assert np.array_equal(_np(dec), rdec) and np.array_equal(_np(fm), rfm), generic
         d2 = torch.zeros_like(yt)
@@ -734,7 +735,7 @@ def test_eval_by_word_online_meta_runs(golden, dev):
         assert torch.isfinite(p).all()
 
 
-def test_nonfinite_samples_like_reference(oracle, dev):
+def test_nonfinite_samples_like_reference(oracle, dev, monkeypatch):
     """NaN / +-inf received samples: the reference turns every branch cost of that symbol into NaN (ViterbiNet: the MLP
     propagates it; VA: (NaN - prior)^2), after which torch.min/argmin leave all metrics NaN and every later decision 0.
     The kernels reproduce that (oracle = torch semantics)."""
@@ -756,10 +757,12 @@ def test_nonfinite_samples_like_reference(oracle, dev):
     assert np.array_equal(_np(det(yt, "val")), rdec)
     assert np.all(rdec[1, 22:] == 0) and np.all(rdec[2, 2:] == 0)  # everything after a NaN sample decodes to 0
     pt = torch.tensor(pri, device=dev)
-    d2 = torch.zeros_like(yt)
-    rc = mvn._lib.load().mvn_va_decode_f32(mvn._lib.ptr(yt), T, mvn._lib.ptr(pt), 1, mvn._lib.ptr(d2), T, None, B, T, S,
-                                           mvn._lib.current_stream(dev))
-    assert rc == 0 and np.array_equal(_np(d2), vdec)
+    for variant in ("rows", "quad"):
+        monkeypatch.setenv("MVN_VA16", variant)
+        d2 = torch.zeros_like(yt)
+        rc = mvn._lib.load().mvn_va_decode_f32(mvn._lib.ptr(yt), T, mvn._lib.ptr(pt), 1, mvn._lib.ptr(d2), T, None, B, T, S,
+                                               mvn._lib.current_stream(dev))
+        assert rc == 0 and np.array_equal(_np(d2), vdec), variant
 
 
 @pytest.mark.parametrize("S", [4, 16, 64, 256])

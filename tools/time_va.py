@@ -28,16 +28,28 @@ for L, B in cases:
         rc = lib.mvn_va_decode_f32(mvn._lib.ptr(y), T, mvn._lib.ptr(pri), 1, mvn._lib.ptr(dec), T, None, B, T, S, st)
         assert rc == 0
 
-    run()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 5
-    e0.record()
-    for _ in range(n):
-        run()
-    e1.record()
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / n
-    c = mvn.count_errors(dec, tx)
-    ser, fer = mvn.rates_from_counters(c)
-    print(f"VA L={L} S={S} B={B} T={T}: {ms:.4f} ms  {B*T/ms/1e6:.3f} Gsym/s  ({B*T*S/ms/1e6:.1f} G state-steps/s)  ser={ser:.4g}")
+    ref = None
+    for variant in (["rows", "quad"] if S == 16 else [""]):
+        if variant:
+            os.environ["MVN_VA16"] = variant
+        dec.zero_()
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 10
+        e0.record()
+        for _ in range(n):
+            run()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        c = mvn.count_errors(dec, tx)
+        ser, fer = mvn.rates_from_counters(c)
+        same = ""
+        if ref is None:
+            ref = dec.clone()
+        else:
+            same = "  == rows" if torch.equal(ref, dec) else "  MISMATCH vs rows"
+        print(f"VA L={L} S={S} B={B} T={T} {variant:5s}: {ms:.4f} ms  {B*T/ms/1e6:.3f} Gsym/s  "
+              f"({B*T*S/ms/1e6:.1f} G state-steps/s)  ser={ser:.4g}{same}", flush=True)
