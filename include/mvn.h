@@ -99,7 +99,8 @@ int mvn_vnet_logits_f32(const float *y, const float *W1, const float *b1, const 
                         int64_t N, int32_t S, mvn_stream_t stream);
 
 /* Bytes of scratch mvn_vnet_decode_f32 wants to run (B,T,S) in one pass; any size that
- * holds at least one block (T*S*4 bytes) is accepted and processed in slices. */
+ * holds at least one block (T*S*4 bytes) is accepted and processed in slices.  0 when the
+ * shape is served by the fused kernel (S = 16), which needs none. */
 size_t mvn_vnet_workspace_bytes(int64_t B, int32_t T, int32_t S);
 
 /*

@@ -720,6 +720,7 @@ int mvn_vnet_logits_f32(const float *y, const float *W1, const float *b1, const 
 
 size_t mvn_vnet_workspace_bytes(int64_t B, int32_t T, int32_t S) {
     if (B <= 0 || T <= 0 || S <= 0) return 0;
+    if (S == 16 && !unfused_forced()) return 0;  // the fused kernel keeps the logits on chip
     return (size_t)B * (size_t)T * (size_t)S * sizeof(float);
 }
 

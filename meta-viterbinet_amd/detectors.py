@@ -135,8 +135,9 @@ def _vnet_val(y: torch.Tensor, params, n_states: int, T: int, return_logits: boo
     ws, ws_bytes = None, 0
     if logits is None:
         ws_bytes = min(int(lib.mvn_vnet_workspace_bytes(B, T, n_states)), _WORKSPACE_CAP)
-        ws_bytes = max(ws_bytes, T * n_states * 4)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=yc.device)
+        if ws_bytes:  # 0: the fused 16-state kernel needs no scratch
+            ws_bytes = max(ws_bytes, T * n_states * 4)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=yc.device)
     with torch.cuda.device(yc.device):
         rc = lib.mvn_vnet_decode_f32(_lib.ptr(yc), Ty, *[_lib.ptr(t) for t in w], _lib.ptr(decoded_word), Ty,
                                      _lib.ptr(logits), None, _lib.ptr(ws), ws_bytes, B, T, n_states,

@@ -63,7 +63,8 @@ def test_argument_validation_needs_no_device(lib):
     # NULL data pointers with work to do
     assert lib.mvn_acs_sweep_f32(None, None, 8, None, 4, 8, 16, None) == -4
     assert lib.mvn_count_errors(None, 4, None, 4, None, 2, 4, None, None) == -4
-    assert lib.mvn_vnet_workspace_bytes(10, 100, 16) == 10 * 100 * 16 * 4
+    assert lib.mvn_vnet_workspace_bytes(10, 100, 4) == 10 * 100 * 4 * 4
+    assert lib.mvn_vnet_workspace_bytes(10, 100, 16) == 0  # fused kernel: logits never leave the chip
 
 
 def test_no_cpu_fallback_in_product_path():
