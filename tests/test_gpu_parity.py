@@ -674,6 +674,39 @@ def test_decode_is_graph_capturable(oracle, dev):
         assert counters.tolist() == oracle.count_errors(rdec, tx).tolist()
 
 
+def test_integration_md_ctypes_stub(oracle, dev):
+    """The reference-side ctypes binding printed in INTEGRATION.md (section B) is executable as written: paste it into
+    a module holding the reference's VNETDetector skeleton and it decodes like the oracle for 16 and 4 states."""
+    import os
+    import re
+
+    import torch.nn as nn
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"## B\..*?```python\n(.*?)```", md, re.S).group(1)
+    block = block.replace("/path/to/meta-viterbinet_amd/libmvn_hip.so", mvn._lib.LIB_PATH)
+    init = ("    def __init__(self, n_states, transmission_lengths):\n"
+            "        super().__init__()\n"
+            "        self.n_states, self.transmission_lengths = n_states, transmission_lengths\n"
+            "        self.net = nn.Sequential(nn.Linear(1, 100), nn.Sigmoid(), nn.Linear(100, 50), nn.ReLU(),\n"
+            "                                 nn.Linear(50, n_states))\n")
+    assert "    ...\n" in block
+    ns = {"nn": nn}
+    exec(compile(block.replace("    ...\n", init, 1), "INTEGRATION.md", "exec"), ns)
+    rng = np.random.RandomState(8)
+    for S, B, T in ((16, 9, 77), (4, 5, 40)):
+        w = _rand_weights(S, rng)
+        det = ns["VNETDetector"](S, {"train": T, "val": T}).to(dev)
+        with torch.no_grad():
+            for p_, a in zip(det.parameters(), w):
+                p_.copy_(torch.tensor(a))
+        y = rng.normal(0, 1.3, (B, T)).astype(np.float32)
+        with torch.cuda.device(dev):
+            got = det(torch.tensor(y, device=dev), "val")
+        assert np.array_equal(_np(got), oracle.vnet_decode(y, w)), S
+
+
 def test_c_abi_demo(oracle, dev, tmp_path):
     """examples/c_abi_demo.cpp binds include/mvn.h from plain C++ (no torch): same decisions and counters as the oracle."""
     import os
