@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <math.h>
 
 #include <type_traits>
 
@@ -784,8 +785,8 @@ int mvn_vnet_online_train_f32(const float *y, const int32_t *labels, int32_t T, 
                                        (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(online_train_kernel, dim3(1), dim3(kTrainThreads), lds, (hipStream_t)stream, y, labels, T, batch_idx,
-                       M, n_iter, W1, b1, W2, b2, W3, b3, adam_m, adam_v, (long long)step0, lr, beta1, beta2, eps, loss_out,
-                       S);
+                       M, n_iter, W1, b1, W2, b2, W3, b3, adam_m, adam_v, pow((double)beta1, (double)step0),
+                       pow((double)beta2, (double)step0), lr, beta1, beta2, eps, loss_out, S, (int)online_train_lds_floats(S));
     return (int)hipGetLastError();
 }
 
