@@ -287,6 +287,18 @@ def test_sweep16_quad_variant(oracle, dev, monkeypatch):
         assert lib.mvn_acs_sweep_f32(mvn._lib.ptr(ct), mvn._lib.ptr(dec), ld, mvn._lib.ptr(fm), B, T, S, st) == 0
         assert np.array_equal(_np(dec[:, :T]), rdec) and np.array_equal(_np(fm), rfm), ld
         assert bool((dec[:, T:] == 7.0).all())  # nothing written past T
+    # classical VA at the same batch size: va16_quad_kernel by default (>= 6 000 blocks), 2 prior rows (B % Bp == 0)
+    y = rng.normal(0, 1.5, (B, T)).astype(np.float32)
+    pri = rng.normal(0, 1, (2, S)).astype(np.float32)
+    vdec, vfm = oracle.va_decode(y, pri)
+    yt, pt = torch.tensor(y, device=dev), torch.tensor(pri, device=dev)
+    for ld in (T + 2, T + 1):
+        dec = torch.full((B, ld), 7.0, device=dev)
+        fm = torch.empty(B, S, device=dev)
+        assert lib.mvn_va_decode_f32(mvn._lib.ptr(yt), T, mvn._lib.ptr(pt), 2, mvn._lib.ptr(dec), ld, mvn._lib.ptr(fm),
+                                     B, T, S, st) == 0
+        assert np.array_equal(_np(dec[:, :T]), vdec) and np.array_equal(_np(fm), vfm), ld
+        assert bool((dec[:, T:] == 7.0).all())
     monkeypatch.setenv("MVN_SWEEP16", "quad")
     monkeypatch.setenv("MVN_UNFUSED", "1")
     w = _rand_weights(S, rng)
