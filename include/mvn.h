@@ -10,6 +10,8 @@
  *   - every pointer is a DEVICE pointer unless stated otherwise; the caller owns all memory;
  *   - fp32 row-major; `*_ld` = row stride in elements; S = n_states = 2**memory_length,
  *     a power of two in [2,256] (the reference's np.uint8 bound, va_detector.py:43);
+ *   - pointers need their type's natural alignment only (4 bytes for fp32); 16-byte aligned
+ *     buffers and row strides that are multiples of 4 get the vector load/store paths;
  *   - calls enqueue work on `stream` (a hipStream_t; NULL = default stream) and return
  *     immediately: they never allocate, free or synchronise, so they can be graph-captured;
  *   - return value: 0 = ok, <0 = bad argument (MVN_E_*), >0 = hipError_t of the failed launch.

@@ -598,7 +598,8 @@ int dispatch_sweep(const float *src, int64_t src_ld, const float *priors, int64_
                    float *final_metric, int64_t B, int T, int S, hipStream_t st) {
     if (S == 16 && !generic_sweep_forced()) {
         if constexpr (MODE != MODE_VA) {  // materialised costs: stream them through LDS in 1-KB pieces
-            const char v = sweep16_variant(B);
+            // the LDS-DMA kernels move 16-byte pieces: a cost tensor that is not 16-byte aligned takes the row kernel
+            const char v = (reinterpret_cast<uintptr_t>(src) & 15) ? 'r' : sweep16_variant(B);
             if (v == 'q') return launch_sweep16_quad<MODE>(src, dec, dec_ld, final_metric, B, T, st);
             if (v != 'r') return launch_sweep16_lds<MODE>(src, dec, dec_ld, final_metric, B, T, st);
         }

@@ -287,6 +287,14 @@ def test_sweep16_quad_variant(oracle, dev, monkeypatch):
         assert lib.mvn_acs_sweep_f32(mvn._lib.ptr(ct), mvn._lib.ptr(dec), ld, mvn._lib.ptr(fm), B, T, S, st) == 0
         assert np.array_equal(_np(dec[:, :T]), rdec) and np.array_equal(_np(fm), rfm), ld
         assert bool((dec[:, T:] == 7.0).all())  # nothing written past T
+    # a cost tensor that is only 4-byte aligned (a view one float into a buffer) must still decode correctly
+    buf = torch.empty(B * T * S + 1, device=dev)
+    mis = buf[1:].view(B, T, S)
+    mis.copy_(ct)
+    assert mis.data_ptr() % 16 == 4
+    dec = torch.zeros(B, T, device=dev)
+    assert lib.mvn_acs_sweep_f32(mvn._lib.ptr(mis), mvn._lib.ptr(dec), T, None, B, T, S, st) == 0
+    assert np.array_equal(_np(dec), rdec)
     # classical VA at the same batch size: va16_quad_kernel by default (>= 6 000 blocks), 2 prior rows (B % Bp == 0)
     y = rng.normal(0, 1.5, (B, T)).astype(np.float32)
     pri = rng.normal(0, 1, (2, S)).astype(np.float32)
@@ -305,6 +313,43 @@ def test_sweep16_quad_variant(oracle, dev, monkeypatch):
     y = rng.normal(0, 1.5, (37, 70)).astype(np.float32)
     got = _vnet_with(w, S, 70, dev)(torch.tensor(y, device=dev), "val")
     assert np.array_equal(_np(got), oracle.vnet_decode(y, w))
+
+
+def test_four_byte_aligned_buffers(oracle, dev):
+    """The ABI asks for 4-byte aligned fp32 pointers only (16-byte alignment merely enables the vector paths): y, dec,
+    tx and the logits may all start one float into their allocations."""
+    S, B, T = 16, 21, 83
+    rng = np.random.RandomState(12)
+    w = _rand_weights(S, rng)
+    wt = _weights_t(w, dev)
+    y = rng.normal(0, 1.2, (B, T)).astype(np.float32)
+    tx = rng.randint(0, 2, (B, T)).astype(np.float32)
+
+    def off1(a):  # same values, storage shifted by 4 bytes
+        buf = torch.empty(a.size + 1, device=dev)
+        v = buf[1:].view(*a.shape)
+        v.copy_(torch.tensor(a))
+        assert v.data_ptr() % 16 == 4
+        return v
+
+    lib, st = mvn._lib.load(), mvn._lib.current_stream(dev)
+    yt, txt = off1(y), off1(tx)
+    dec, lg = off1(np.zeros((B, T), np.float32)), off1(np.zeros((B, T, S), np.float32))
+    rdec, rlg = oracle.vnet_decode(y, w, want_logits=True)
+    rc = lib.mvn_vnet_decode_f32(mvn._lib.ptr(yt), T, *[mvn._lib.ptr(t) for t in wt], mvn._lib.ptr(dec), T,
+                                 mvn._lib.ptr(lg), None, None, 0, B, T, S, st)
+    assert rc == 0 and np.array_equal(_np(dec), rdec) and np.array_equal(_np(lg), rlg)
+    lg2 = off1(np.zeros((B * T, S), np.float32))
+    rc = lib.mvn_vnet_logits_f32(mvn._lib.ptr(yt.reshape(-1)), *[mvn._lib.ptr(t) for t in wt], mvn._lib.ptr(lg2), B * T, S, st)
+    assert rc == 0 and np.array_equal(_np(lg2).reshape(B, T, S), rlg)
+    c = torch.zeros(4, dtype=torch.int64, device=dev)
+    rc = lib.mvn_count_errors(mvn._lib.ptr(dec), T, mvn._lib.ptr(txt), T, None, B, T, mvn._lib.ptr(c), st)
+    assert rc == 0 and c.tolist() == oracle.count_errors(rdec, tx).tolist()
+    pri = rng.normal(0, 1, (1, S)).astype(np.float32)
+    d2 = off1(np.zeros((B, T), np.float32))
+    rc = lib.mvn_va_decode_f32(mvn._lib.ptr(yt), T, mvn._lib.ptr(torch.tensor(pri, device=dev)), 1, mvn._lib.ptr(d2), T, None,
+                               B, T, S, st)
+    assert rc == 0 and np.array_equal(_np(d2), oracle.va_decode(y, pri, want_final=False))
 
 
 def test_vnet_workspace_slicing(oracle, dev, monkeypatch):
