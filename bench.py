@@ -159,6 +159,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if world > 1:
+        all_reduce(counters)  # untimed: the first int64 all-reduce sets up RCCL's channels / kernels for this shape
     counters.zero_()
     torch.cuda.synchronize(dev)
     if world > 1:
