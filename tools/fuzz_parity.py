@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the HIP path against the CPU oracle (not part of the pytest suite: run on a GPU box,
+`python tools/fuzz_parity.py [seconds] [seed]`).  Random shapes, row strides, kernel variants (environment switches),
+tie-heavy integer costs, occasional non-finite samples; every decision, final metric and logit must match bit for bit."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import meta_viterbinet_amd as mvn  # noqa: E402
+import oracle  # noqa: E402  (test infrastructure: the checker)
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = torch.device("cuda:0")
+lib, st, ptr = mvn._lib.load(), mvn._lib.current_stream(dev), mvn._lib.ptr
+ENV = ["MVN_SWEEP16", "MVN_VA16", "MVN_GENERIC_SWEEP", "MVN_UNFUSED", "MVN_FUSED4", "MVN_FUSED_LDSW"]
+
+
+def strided(a, pad):
+    """device copy of a 2-D array inside a wider buffer (row stride = cols + pad)"""
+    buf = torch.full((a.shape[0], a.shape[1] + pad), 9.0, device=dev)
+    buf[:, : a.shape[1]] = torch.tensor(a, device=dev)
+    return buf
+
+
+def rand_weights(S):
+    return [rng.normal(0, s, sh).astype(np.float32) for s, sh in
+            ((1.5, (100, 1)), (1.0, (100,)), (0.3, (50, 100)), (0.3, (50,)), (0.4, (S, 50)), (0.3, (S,)))]
+
+
+n, t_end, kinds = 0, time.time() + budget, {"sweep": 0, "va": 0, "vnet": 0}
+while time.time() < t_end:
+    for k in ENV:
+        os.environ.pop(k, None)
+    S = int(2 ** rng.randint(1, 9))
+    big = rng.rand() < 0.1
+    B = int(rng.randint(6000, 9000)) if (big and S == 16) else int(rng.randint(1, 300))
+    T = int(rng.randint(1, 40)) if big else int(rng.randint(1, 200))
+    pad_y, pad_d = int(rng.randint(0, 5)), int(rng.randint(0, 5))
+    if S == 16:
+        os.environ["MVN_SWEEP16"] = str(rng.choice(["rows", "lds", "quad"]))
+        os.environ["MVN_VA16"] = str(rng.choice(["rows", "quad"]))
+        os.environ["MVN_FUSED4"] = str(rng.choice(["0", "1"]))
+        os.environ["MVN_FUSED_LDSW"] = str(rng.choice(["0", "1"]))
+    if rng.rand() < 0.25:
+        os.environ["MVN_GENERIC_SWEEP"] = "1"
+    if rng.rand() < 0.3:
+        os.environ["MVN_UNFUSED"] = "1"
+    kind = str(rng.choice(["sweep", "va", "vnet"]))
+    y = rng.normal(0, 1.5, (B, T)).astype(np.float32)
+    if rng.rand() < 0.15:
+        y[rng.randint(B), rng.randint(T)] = rng.choice([np.nan, np.inf, -np.inf])
+    yt = strided(y, pad_y)
+    dec = torch.full((B, T + pad_d), 7.0, device=dev)
+    fm = torch.empty(B, S, device=dev)
+    tag = f"{kind} S={S} B={B} T={T} pads=({pad_y},{pad_d}) env={ {k: os.environ[k] for k in ENV if k in os.environ} }"
+    with np.errstate(all="ignore"):
+        if kind == "sweep":
+            cost = rng.normal(0, 2, (B, T, S)).astype(np.float32)
+            if rng.rand() < 0.5:
+                cost = np.round(cost)  # exact ties between states
+            rdec, rfm = oracle.acs_sweep(cost)
+            ct = torch.tensor(cost, device=dev)
+            rc = lib.mvn_acs_sweep_f32(ptr(ct), ptr(dec), T + pad_d, ptr(fm), B, T, S, st)
+        elif kind == "va":
+            Bp = int(rng.choice([1, B]))
+            pri = rng.normal(0, 1, (Bp, S)).astype(np.float32)
+            rdec, rfm = oracle.va_decode(y, pri)
+            pt = torch.tensor(pri, device=dev)
+            rc = lib.mvn_va_decode_f32(ptr(yt), T + pad_y, ptr(pt), Bp, ptr(dec), T + pad_d, ptr(fm), B, T, S, st)
+        else:
+            w = rand_weights(S)
+            rdec, rlg, rfm = oracle.vnet_decode(y, w, want_logits=True, want_final=True)
+            wt = [torch.tensor(a, device=dev) for a in w]
+            lg = torch.empty(B, T, S, device=dev)
+            rc = lib.mvn_vnet_decode_f32(ptr(yt), T + pad_y, *[ptr(a) for a in wt], ptr(dec), T + pad_d, ptr(lg), ptr(fm),
+                                         None, 0, B, T, S, st)
+    torch.cuda.synchronize()
+    assert rc == 0, (rc, tag)
+    got = dec[:, :T].cpu().numpy()
+    nonfinite = not np.isfinite(y).all()
+    assert np.array_equal(got, rdec[:, :T]), tag
+    assert bool((dec[:, T:] == 7.0).all()), tag
+    if not nonfinite or kind == "sweep":
+        assert np.array_equal(fm.cpu().numpy(), rfm, equal_nan=True), tag
+    if kind == "vnet" and not nonfinite:
+        assert np.array_equal(lg.cpu().numpy(), rlg), tag
+    n += 1
+    kinds[kind] += 1
+print(f"fuzz_parity: {n} random cases bit-identical to the oracle in {budget:.0f} s  {kinds}")
