@@ -93,4 +93,6 @@ while time.time() < t_end:
         assert np.array_equal(lg.cpu().numpy(), rlg), tag
     n += 1
     kinds[kind] += 1
+    if n % 2000 == 0:
+        print(f"  ... {n} cases ok", flush=True)
 print(f"fuzz_parity: {n} random cases bit-identical to the oracle in {budget:.0f} s  {kinds}")
