@@ -382,7 +382,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 #include "sweep16_lds.inc"
 #include "sweep16_quad.inc"
 #include "va16_quad.inc"
-#include "va256_inplace.inc"
+#include "va_inplace.inc"
 #include "rs_codec.inc"
 #include "online_train.inc"
 
@@ -596,6 +596,13 @@ char sweep16_variant(int64_t B) {
 template <int MODE>
 int dispatch_sweep(const float *src, int64_t src_ld, const float *priors, int64_t Bp, float *dec, int64_t dec_ld,
                    float *final_metric, int64_t B, int T, int S, hipStream_t st) {
+    if constexpr (MODE == MODE_VA) {
+        // classical VA: the lane-bits x register-bits in-place kernel serves every S >= 4 except S = 16, which has its
+        // own 16-blocks-per-wave / row kernels below (MVN_VA_INPLACE=1 sends S = 16 here too, for cross-checks)
+        const char *e = getenv("MVN_VA_INPLACE");
+        if (S >= 4 && !generic_sweep_forced() && (S != 16 || (e && e[0] == '1')))
+            return launch_va_inplace(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, S, st);
+    }
     if (S == 16 && !generic_sweep_forced()) {
         if constexpr (MODE != MODE_VA) {  // materialised costs: stream them through LDS in 1-KB pieces
             // the LDS-DMA kernels move 16-byte pieces: a cost tensor that is not 16-byte aligned takes the row kernel
@@ -609,10 +616,6 @@ int dispatch_sweep(const float *src, int64_t src_ld, const float *priors, int64_
                 return launch_va16_quad(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
         }
         return launch_sweep16_rows<MODE>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
-    }
-    if constexpr (MODE == MODE_VA) {
-        if (S == 256 && !generic_sweep_forced())
-            return launch_va256_inplace(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
     }
     return launch_sweep<MODE>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, S, st);
 }

@@ -672,29 +672,32 @@ def test_eval_by_word_self_supervised_tracks_channel(golden, dev):
     assert ser_online[100:].mean() <= ser_frozen[100:].mean() + 2e-3
 
 
-@pytest.mark.parametrize("B,T", [(1, 1), (2, 7), (3, 8), (5, 63), (4, 64), (6, 65), (33, 200), (9, 1000)])
-def test_va256_inplace_and_generic_paths(oracle, dev, monkeypatch, B, T):
-    """L=8 (256 states): the in-place wave-per-block kernel and the generic LDS sweep (MVN_GENERIC_SWEEP=1) both match
-    the oracle bit for bit, decisions and final path metrics, for every chunk/phase remainder."""
-    S = 256
-    rng = np.random.RandomState(B * 1000 + T)
+@pytest.mark.parametrize("L", [2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("B,T", [(1, 1), (2, 7), (3, 8), (5, 63), (4, 64), (70, 65), (33, 200), (9, 1000)])
+def test_va_inplace_and_generic_paths(oracle, dev, monkeypatch, L, B, T):
+    """Classical VA for every memory length: the lane-bits x register-bits in-place kernel (default for S >= 4 except
+    S = 16, forced there by MVN_VA_INPLACE=1) and the generic LDS-exchange sweep (MVN_GENERIC_SWEEP=1) both match the
+    oracle bit for bit, decisions and final path metrics, for every chunk / phase remainder and a partial last wave."""
+    S = 2 ** L
+    rng = np.random.RandomState(B * 1000 + T + L)
     y = rng.normal(0, 1.5, (B, T)).astype(np.float32)
     if B > 1:
         y[1] = 0.0
-    h = mvn.estimate_channel(8, 0.2, "time_decay")
-    sym = 1 - 2 * ((np.arange(S)[:, None] >> np.arange(8)[::-1]) & 1)
-    pri = (sym @ h.T).T.astype(np.float32)  # [1,256], antisymmetric: systematic ties at y = 0
+    h = mvn.estimate_channel(L, 0.2, "time_decay")
+    sym = 1 - 2 * ((np.arange(S)[:, None] >> np.arange(L)[::-1]) & 1)
+    pri = (sym @ h.T).T.astype(np.float32)  # [1,S], antisymmetric: systematic ties at y = 0
     rdec, rfm = oracle.va_decode(y, pri)
     yt, pt = torch.tensor(y, device=dev), torch.tensor(pri, device=dev)
-    for generic in ("0", "1"):
+    for generic, inplace in (("0", "1"), ("1", "0")):
         monkeypatch.setenv("MVN_GENERIC_SWEEP", generic)
+        monkeypatch.setenv("MVN_VA_INPLACE", inplace)
         dec = torch.zeros_like(yt)
         fm = torch.empty(B, S, device=dev)
         rc = mvn._lib.load().mvn_va_decode_f32(mvn._lib.ptr(yt), T, mvn._lib.ptr(pt), 1, mvn._lib.ptr(dec), T,
                                                mvn._lib.ptr(fm), B, T, S, mvn._lib.current_stream(dev))
         assert rc == 0
-        assert np.array_equal(_np(dec), rdec), generic
-        assert np.array_equal(_np(fm), rfm), generic
+        assert np.array_equal(_np(dec), rdec), (generic, inplace)
+        assert np.array_equal(_np(fm), rfm), (generic, inplace)
 
 
 def test_decode_is_graph_capturable(oracle, dev):

@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 lib = mvn._lib.load()
 st = mvn._lib.current_stream(dev)
 T = 1000
-cases = [(4, 100), (4, 10000), (4, 200000), (8, 2000), (8, 20000), (2, 100000), (6, 20000)]
+cases = [(4, 100), (4, 10000), (4, 200000), (8, 2000), (8, 20000), (2, 100000), (3, 100000), (5, 50000), (6, 20000), (7, 20000)]
 if len(sys.argv) > 1:
     cases = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
 for L, B in cases:
@@ -29,9 +29,15 @@ for L, B in cases:
         assert rc == 0
 
     ref = None
-    for variant in (["rows", "quad"] if S == 16 else [""]):
-        if variant:
+    for variant in (["rows", "quad", "tmpl"] if S == 16 else ["tmpl", "generic"] if S >= 4 else [""]):
+        os.environ.pop("MVN_VA_INPLACE", None)
+        os.environ.pop("MVN_GENERIC_SWEEP", None)
+        if variant in ("rows", "quad"):
             os.environ["MVN_VA16"] = variant
+        elif variant == "tmpl":
+            os.environ["MVN_VA_INPLACE"] = "1"
+        elif variant == "generic":
+            os.environ["MVN_GENERIC_SWEEP"] = "1"
         dec.zero_()
         for _ in range(3):
             run()
@@ -50,6 +56,6 @@ for L, B in cases:
         if ref is None:
             ref = dec.clone()
         else:
-            same = "  == rows" if torch.equal(ref, dec) else "  MISMATCH vs rows"
-        print(f"VA L={L} S={S} B={B} T={T} {variant:5s}: {ms:.4f} ms  {B*T/ms/1e6:.3f} Gsym/s  "
+            same = "  == first" if torch.equal(ref, dec) else "  MISMATCH vs first"
+        print(f"VA L={L} S={S} B={B} T={T} {variant:7s}: {ms:.4f} ms  {B*T/ms/1e6:.3f} Gsym/s  "
               f"({B*T*S/ms/1e6:.1f} G state-steps/s)  ser={ser:.4g}{same}", flush=True)
