@@ -11,6 +11,11 @@
 //   mlp_kernel<NT3>        ViterbiNet MLP (vnet_detector.py:27-33,49) on f32 MFMA 16x16x4:
 //                          exact k-ordered fmaf chains == torch-CPU sgemm result order.
 //   count_errors_kernel    metrics.py:7-17 as int64 counters.
+// and, in the .inc files included below (each starts with its own description):
+//   vnet16_fused4.inc / vnet16_fused.inc   fused ViterbiNet detector at 16 states (MLP on MFMA + in-place DPP sweep)
+//   sweep16_rows / _lds / _quad.inc        16-state sweeps over materialised costs (register prefetch, LDS-DMA)
+//   va16_quad.inc, va_inplace.inc          fused classical Viterbi (16 states; any S >= 4)
+//   rs_codec.inc, online_train.inc         Reed-Solomon encode/decode, one-launch online training
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
