@@ -6,7 +6,7 @@ from .detectors import HIDDEN1_SIZE, HIDDEN2_SIZE, META_VNETDetector, VADetector
 from .ecc import rs_decode, rs_encode
 from .harness import (data_indices, detect_by_word, eval_by_word, eval_counters, shard_range, sharded_eval,
                       single_eval_at_point, synthetic_words)
-from .meta import copy_model, meta_train_loop
+from .meta import GraphedMetaStep, copy_model, meta_train_loop
 from .online import OnlineTrainer
 from .metrics import calculate_error_rates, count_errors, rates_from_counters
 from .trellis import acs_block, acs_sweep, calculate_states, create_transition_table
@@ -15,7 +15,7 @@ __all__ = [
     "VADetector", "VNETDetector", "META_VNETDetector", "HIDDEN1_SIZE", "HIDDEN2_SIZE",
     "create_transition_table", "acs_block", "acs_sweep", "calculate_states",
     "calculate_error_rates", "count_errors", "rates_from_counters",
-    "estimate_channel", "BPSKModulator", "transmit", "rs_encode", "rs_decode", "OnlineTrainer", "meta_train_loop", "copy_model",
+    "estimate_channel", "BPSKModulator", "transmit", "rs_encode", "rs_decode", "OnlineTrainer", "meta_train_loop", "GraphedMetaStep", "copy_model",
     "shard_range", "data_indices", "synthetic_words", "eval_counters", "single_eval_at_point",
     "sharded_eval", "detect_by_word", "eval_by_word",
 ]

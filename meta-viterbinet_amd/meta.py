@@ -36,3 +36,63 @@ def meta_train_loop(detector, meta_detector, online_trainer, received_words: tor
     meta_grad = torch.autograd.grad(loss_query, params, create_graph=False)
     online_trainer.adam_step(meta_grad)
     return loss_query.detach()
+
+
+class GraphedMetaStep:
+    """meta_train_loop as ONE hipGraph replay (torch.cuda.CUDAGraph): the ~200 small ATen kernels of a second-order MAML
+    step (forward, double backward, Adam) are captured once for a given (support words, word length) shape and replayed
+    per step with the (support, query) words copied into static buffers.  Same kernels in the same order as the eager
+    function, so the arithmetic is the same up to the form of the Adam update (OnlineTrainer.adam_step_device)."""
+
+    def __init__(self, detector, meta_detector, online_trainer, n_support: int, T: int, meta_lr: float, MAML: bool = True):
+        self.detector, self.meta_detector, self.tr = detector, meta_detector, online_trainer
+        self.meta_lr, self.MAML = meta_lr, MAML
+        params = list(detector.parameters())
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise ValueError("GraphedMetaStep needs the detector on the GPU")
+        self.s_rx, self.s_tx = torch.zeros(n_support, T, device=dev), torch.zeros(n_support, T, device=dev)
+        self.q_rx, self.q_tx = torch.zeros(1, T, device=dev), torch.zeros(1, T, device=dev)
+        self.step_t = torch.zeros((), dtype=torch.float64, device=dev)
+        self.loss = torch.zeros((), device=dev)
+        # the warm-up passes torch asks for before a capture execute for real: put the state back afterwards
+        snap = [p.detach().clone() for p in params] + [online_trainer.exp_avg.clone(), online_trainer.exp_avg_sq.clone()]
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+        with torch.no_grad():
+            for p, a in zip(params, snap):
+                p.copy_(a)
+            online_trainer.exp_avg.copy_(snap[-2])
+            online_trainer.exp_avg_sq.copy_(snap[-1])
+
+    def _body(self):
+        with torch.enable_grad():
+            params = list(self.detector.parameters())
+            soft_supp = self.meta_detector(self.s_rx, "train", params)
+            loss_supp = states_loss(soft_supp, self.s_tx, self.tr.memory_length)
+            local_grad = torch.autograd.grad(loss_supp, params, create_graph=self.MAML)
+            updated = [p - self.meta_lr * g for g, p in zip(local_grad, params)]
+            soft_query = self.meta_detector(self.q_rx, "train", updated)
+            loss_query = states_loss(soft_query, self.q_tx, self.tr.memory_length)
+            meta_grad = torch.autograd.grad(loss_query, params, create_graph=False)
+        self.tr.adam_step_device(meta_grad, self.step_t)
+        self.loss.copy_(loss_query.detach())
+
+    def __call__(self, received_words: torch.Tensor, transmitted_words: torch.Tensor, support_idx: torch.Tensor,
+                 query_idx: torch.Tensor) -> torch.Tensor:
+        """One MAML step on words picked from the buffers (indices may be negative, like the reference's)."""
+        self.s_rx.copy_(received_words[support_idx])
+        self.s_tx.copy_(transmitted_words[support_idx])
+        self.q_rx.copy_(received_words[query_idx])
+        self.q_tx.copy_(transmitted_words[query_idx])
+        self.step_t.fill_(float(self.tr.step))
+        self.graph.replay()
+        self.tr.step += 1
+        return self.loss

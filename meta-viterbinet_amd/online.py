@@ -43,6 +43,27 @@ class OnlineTrainer:
             p.data.addcdiv_(m, denom, value=-step_size)
             off += n
 
+    @torch.no_grad()
+    def adam_step_device(self, grads, step_t: torch.Tensor):
+        """adam_step with the step counter and the bias corrections on the device (`step_t`: 0-d float64 tensor holding
+        the number of steps taken so far), so that the whole update can sit inside a captured hipGraph
+        (meta.GraphedMetaStep).  The caller keeps `self.step` in sync."""
+        b1, b2 = self.betas
+        step_t.add_(1.0)
+        bc1 = 1.0 - torch.pow(b1, step_t)
+        bc2 = 1.0 - torch.pow(b2, step_t)
+        step_size = (self.lr / bc1).to(torch.float32)
+        bc2_sqrt = torch.sqrt(bc2).to(torch.float32)
+        off = 0
+        for p, g in zip(self.params, grads):
+            n = p.numel()
+            m, v = self.exp_avg[off:off + n].view_as(p), self.exp_avg_sq[off:off + n].view_as(p)
+            m.mul_(b1).add_(g, alpha=1.0 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+            denom = (v.sqrt() / bc2_sqrt).add_(self.eps)
+            p.data.sub_((m / denom) * step_size)
+            off += n
+
     def select_batches(self, T: int, iterations: int) -> torch.Tensor:
         """`iterations` minibatches drawn like select_batch (trainer.py:542): torch.multinomial with weights
         arange(T) (sample 0 is never drawn), without replacement, all iterations in one call."""

@@ -828,6 +828,41 @@ def test_eval_by_word_online_meta_runs(golden, dev):
         assert torch.isfinite(p).all()
 
 
+@pytest.mark.parametrize("MAML", [True, False])
+def test_graphed_meta_step_matches_eager(golden, dev, MAML):
+    """meta.GraphedMetaStep (the MAML step of trainer.py:425-453 replayed from a hipGraph) against the eager
+    meta_train_loop on the same words: same kernels in the same order, so parameters, Adam moments and step counter agree
+    to rounding of the Adam update (tolerance 1e-6 relative) after 7 steps; capturing must leave the state untouched."""
+    g7 = golden("g7_by_word")
+    w = [g7[f"w{i}"] for i in range(6)]
+    T, L, S = 136, 4, 16
+    gen = torch.Generator(device=dev).manual_seed(3)
+    rxw = torch.randn(6, T, generator=gen, device=dev)
+    txw = torch.randint(0, 2, (6, T), generator=gen, device=dev).float()
+    dets, trs = [_vnet_with(w, S, T, dev) for _ in range(2)], []
+    meta = mvn.META_VNETDetector(S, {"train": T, "val": T})
+    for d in dets:
+        trs.append(mvn.OnlineTrainer(d, L))
+        trs[-1].step = 11  # a non-trivial bias correction
+        trs[-1].exp_avg.normal_(0, 1e-3, generator=gen)
+        trs[-1].exp_avg_sq.uniform_(1e-7, 1e-5, generator=gen)
+    trs[1].exp_avg.copy_(trs[0].exp_avg)
+    trs[1].exp_avg_sq.copy_(trs[0].exp_avg_sq)
+    graphed = mvn.GraphedMetaStep(dets[1], meta, trs[1], 1, T, 0.1, MAML)
+    assert trs[1].step == 11 and torch.equal(trs[1].exp_avg, trs[0].exp_avg)
+    for a, b in zip(dets[0].parameters(), dets[1].parameters()):
+        assert torch.equal(a, b)
+    for k in range(7):
+        sup, qry = torch.tensor([k % 5 - 1], device=dev), torch.tensor([k % 5], device=dev)  # includes index -1
+        l0 = mvn.meta_train_loop(dets[0], meta, trs[0], rxw, txw, sup, qry, 0.1, MAML)
+        l1 = graphed(rxw, txw, sup, qry)
+        assert abs(float(l0) - float(l1)) <= 1e-6 * abs(float(l0))
+    assert trs[0].step == trs[1].step == 18
+    for a, b in zip(dets[0].parameters(), dets[1].parameters()):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-8)
+    assert torch.allclose(trs[0].exp_avg, trs[1].exp_avg, rtol=1e-5, atol=1e-7)
+
+
 def test_nonfinite_samples_like_reference(oracle, dev, monkeypatch):
     """NaN / +-inf received samples: the reference turns every branch cost of that symbol into NaN (ViterbiNet: the MLP
     propagates it; VA: (NaN - prior)^2), after which torch.min/argmin leave all metrics NaN and every later decision 0.
