@@ -162,6 +162,23 @@ int mvn_vnet_online_train_f32(const float *y, const int32_t *labels, int32_t T, 
                               float *loss_out, int32_t S, mvn_stream_t stream);
 
 /*
+ * n_steps online meta-learning steps of Meta-ViterbiNet in ONE launch: Trainer.meta_train_loop
+ * (python_code/trainers/trainer.py:425-453) with METAVNETTrainer.calc_loss (metavnet_trainer.py:41-50):
+ *   inner SGD step on the support words (lr = meta_lr), query loss through the updated weights, meta-gradient w.r.t.
+ *   the original weights (second_order != 0: MAML with the exact Hessian-vector product; 0: first order), one Adam step.
+ *   rx_words [Nw, T] fp32 received words and labels [Nw, T] int32 trellis states (calculate_states of the buffered
+ *   transmitted words); step k uses the W words support_idx[k*W .. k*W+W-1] and the word query_idx[k] (indices into
+ *   the Nw words, already non-negative); weights, adam_m/adam_v [P] and step0 as in mvn_vnet_online_train_f32 (the
+ *   reference has one optimizer for both loops); loss_out [n_steps] query losses or NULL.  S <= 32.
+ * fp32, deterministic; agrees with torch's double backward + Adam to rounding (tolerance in the tests).
+ */
+int mvn_vnet_maml_train_f32(const float *rx_words, const int32_t *labels, int32_t T, const int32_t *support_idx, int32_t W,
+                            const int32_t *query_idx, int32_t n_steps, float *W1, float *b1, float *W2, float *b2,
+                            float *W3, float *b3, float *adam_m, float *adam_v, int64_t step0, float meta_lr,
+                            int32_t second_order, float lr, float beta1, float beta2, float eps, float *loss_out, int32_t S,
+                            mvn_stream_t stream);
+
+/*
  * ISI-AWGN channel: ChannelModelDataset.transmit / ISIAWGNChannel.transmit,
  * python_code/channel/channel_dataset.py:71,87-95 + channel.py:12-35 + modulator.py:12:
  *   y[b,t] = sum_i h[b % Bh][L-1-i] * (1 - 2 c[b,t+i]) + sigma * w[b,t],   c = bits zero-padded past K,

@@ -33,6 +33,8 @@ SIGNATURES = {
                                                  _i64, _i32, _i32, _vp]),
     "mvn_vnet_online_train_f32": (ctypes.c_int, [_vp, _vp, _i32, _vp, _i32, _i32] + [_vp] * 8 +
                                   [_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _i32, _vp]),
+    "mvn_vnet_maml_train_f32": (ctypes.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32] + [_vp] * 8 +
+                                [_i64, ctypes.c_float, _i32] + [ctypes.c_float] * 4 + [_vp, _i32, _vp]),
     "mvn_isi_awgn_transmit": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _i64, ctypes.c_double, _vp, _i64, _i64,
                                              _i32, _i32, _vp]),
     "mvn_rs_decode_bits_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),

@@ -15,7 +15,8 @@
 //   vnet16_fused4.inc / vnet16_fused.inc   fused ViterbiNet detector at 16 states (MLP on MFMA + in-place DPP sweep)
 //   sweep16_rows / _lds / _quad.inc        16-state sweeps over materialised costs (register prefetch, LDS-DMA)
 //   va16_quad.inc, va_inplace.inc          fused classical Viterbi (16 states; any S >= 4)
-//   rs_codec.inc, online_train.inc         Reed-Solomon encode/decode, one-launch online training
+//   rs_codec.inc                           Reed-Solomon encode/decode
+//   online_train.inc, maml_train.inc       one-launch online training and MAML meta-learning steps
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -390,6 +391,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 #include "va_inplace.inc"
 #include "rs_codec.inc"
 #include "online_train.inc"
+#include "maml_train.inc"
 
 // -------------------------------------------------------------------------------------------
 // metrics.py:7-17 as integer counters.  One wave per row, block-level reduction, one atomic
@@ -796,6 +798,26 @@ int mvn_vnet_online_train_f32(const float *y, const int32_t *labels, int32_t T, 
     hipLaunchKernelGGL(online_train_kernel, dim3(1), dim3(kTrainThreads), lds, (hipStream_t)stream, y, labels, T, batch_idx,
                        M, n_iter, W1, b1, W2, b2, W3, b3, adam_m, adam_v, pow((double)beta1, (double)step0),
                        pow((double)beta2, (double)step0), lr, beta1, beta2, eps, loss_out, S, (int)online_train_lds_floats(S));
+    return (int)hipGetLastError();
+}
+
+int mvn_vnet_maml_train_f32(const float *rx_words, const int32_t *labels, int32_t T, const int32_t *support_idx, int32_t W,
+                            const int32_t *query_idx, int32_t n_steps, float *W1, float *b1, float *W2, float *b2,
+                            float *W3, float *b3, float *adam_m, float *adam_v, int64_t step0, float meta_lr,
+                            int32_t second_order, float lr, float beta1, float beta2, float eps, float *loss_out, int32_t S,
+                            mvn_stream_t stream) {
+    if (T < 1 || W < 1 || n_steps < 0 || step0 < 0) return MVN_E_DIMS;
+    if (!valid_states(S) || S > 32) return MVN_E_STATES;  // four parameter-sized vectors + a chunk must fit the 160-KB LDS
+    if (n_steps == 0) return MVN_OK;
+    if (!rx_words || !labels || !support_idx || !query_idx || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !adam_m || !adam_v)
+        return MVN_E_NULL;
+    const size_t lds = maml_train_lds_floats(S) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void *)maml_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(maml_train_kernel, dim3(1), dim3(kTrainThreads), lds, (hipStream_t)stream, rx_words, labels, T,
+                       support_idx, W, query_idx, n_steps, W1, b1, W2, b2, W3, b3, adam_m, adam_v,
+                       pow((double)beta1, (double)step0), pow((double)beta2, (double)step0), meta_lr, second_order, lr, beta1,
+                       beta2, eps, loss_out, S, (int)maml_train_lds_floats(S));
     return (int)hipGetLastError();
 }
 

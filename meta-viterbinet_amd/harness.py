@@ -135,7 +135,7 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
                  verbose: bool = False, online_meta: bool = False, meta_detector=None, meta_lr: float = 0.1,
                  MAML: bool = True, window_size: int = 1, meta_train_iterations: int = 20, meta_j_num: int = 10,
                  meta_subframes: int = 5, meta_style_online_training: bool = False,
-                 graphed_meta: bool = True) -> np.ndarray:
+                 graphed_meta: bool = True, hip_meta: bool = True) -> np.ndarray:
     """Sequential per-block online evaluation: counterpart of Trainer.eval_by_word (trainer.py:267-354) with
     buffer_empty=True and weights_init='last_frame'.  Everything but the control flow stays on the GPU:
         for every block k:  detect (B=1)  ->  data block: RS decode, ser, RS re-encode | pilot: encode the known word
@@ -164,6 +164,7 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
     buffer_tx = torch.empty([0, rx.shape[1]], device=rx.device)
     meta_step = None  # meta.GraphedMetaStep, built at the first meta update (graphed_meta and a CUDA detector)
     graphed_meta = graphed_meta and rx.is_cuda
+    hip_meta = hip_meta and rx.is_cuda and detector.n_states <= 32  # mvn_vnet_maml_train_f32 (the LDS holds 4 parameter vectors)
     support_idx = torch.arange(-window_size - 1, -1, device=rx.device).long()  # :288
     query_idx = -1 * torch.ones(1, device=rx.device).long()
     for count in range(N):
@@ -184,16 +185,25 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
             buffer_tx = torch.cat([buffer_tx, detected_word.reshape(1, -1) if ser > 0 else encoded_word.reshape(1, -1)], dim=0)
         if online_meta and count % meta_subframes == 0 and count >= meta_subframes and buffer_rx.shape[0] > 2:  # :331-343
             copy_model(source_model=saved_detector, dest_model=detector)  # weights_init == 'last_frame' (:360-361)
-            if graphed_meta and meta_step is None:  # captured once: one hipGraph replay per MAML step from here on
-                meta_step = GraphedMetaStep(detector, meta_detector, online_trainer, window_size, rx.shape[1], meta_lr, MAML)
-            for _ in range(meta_train_iterations):
-                j_hat_values = torch.unique(torch.randint(low=0, high=buffer_rx.shape[0] - 2, size=[meta_j_num])).to(rx.device)
-                for j_hat in j_hat_values:
-                    if meta_step is not None:
-                        meta_step(buffer_rx, buffer_tx, j_hat + support_idx + 1, j_hat + query_idx + 1)
-                    else:
-                        meta_train_loop(detector, meta_detector, online_trainer, buffer_rx, buffer_tx,
-                                        j_hat + support_idx + 1, j_hat + query_idx + 1, meta_lr, MAML)
+            if hip_meta:  # every MAML step of this update in ONE launch of the meta-learning kernel
+                sup, qry = [], []
+                for _ in range(meta_train_iterations):
+                    j_hat_values = torch.unique(torch.randint(low=0, high=buffer_rx.shape[0] - 2, size=[meta_j_num])).to(rx.device)
+                    sup.append(j_hat_values.reshape(-1, 1) + support_idx.reshape(1, -1) + 1)
+                    qry.append(j_hat_values + query_idx + 1)
+                online_trainer.maml_training(buffer_rx, buffer_tx, torch.cat(sup), torch.cat(qry), meta_lr, MAML)
+            else:
+                if graphed_meta and meta_step is None:  # captured once: one hipGraph replay per MAML step from here on
+                    meta_step = GraphedMetaStep(detector, meta_detector, online_trainer, window_size, rx.shape[1], meta_lr,
+                                                MAML)
+                for _ in range(meta_train_iterations):
+                    j_hat_values = torch.unique(torch.randint(low=0, high=buffer_rx.shape[0] - 2, size=[meta_j_num])).to(rx.device)
+                    for j_hat in j_hat_values:
+                        if meta_step is not None:
+                            meta_step(buffer_rx, buffer_tx, j_hat + support_idx + 1, j_hat + query_idx + 1)
+                        else:
+                            meta_train_loop(detector, meta_detector, online_trainer, buffer_rx, buffer_tx,
+                                            j_hat + support_idx + 1, j_hat + query_idx + 1, meta_lr, MAML)
             copy_model(source_model=detector, dest_model=saved_detector)
         if self_supervised and ser <= ser_thresh:  # :345-347
             if meta_style_online_training:

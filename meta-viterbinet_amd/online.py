@@ -64,6 +64,36 @@ class OnlineTrainer:
             p.data.sub_((m / denom) * step_size)
             off += n
 
+    def maml_training(self, rx_words: torch.Tensor, tx_words: torch.Tensor, support_idx: torch.Tensor,
+                      query_idx: torch.Tensor, meta_lr: float, MAML: bool = True, return_loss: bool = False):
+        """n online meta-learning steps (trainer.py:425-453 = meta.meta_train_loop) in ONE kernel launch.
+        rx_words / tx_words [Nw, T]: buffered received words and their (re-encoded or detected) transmitted words;
+        support_idx [n, W], query_idx [n]: the words of every step (negative indices count from the end, like the
+        reference's fancy indexing).  Uses and advances the same Adam state as online_training."""
+        p = self.params
+        dev = p[0].device
+        _lib.require_gpu_tensor(rx_words, "rx_words")
+        _lib.require_gpu_tensor(p[0], "detector parameters")
+        rx = rx_words.detach().to(torch.float32).contiguous()
+        Nw, T = rx.shape
+        labels = calculate_states(self.memory_length, tx_words.detach().to(dev)).reshape(Nw, T).to(torch.int32).contiguous()
+        sup = torch.remainder(support_idx.to(dev).reshape(query_idx.numel(), -1), Nw).to(torch.int32).contiguous()
+        qry = torch.remainder(query_idx.to(dev).reshape(-1), Nw).to(torch.int32).contiguous()
+        n, W = sup.shape
+        for t in p:
+            if not t.data.is_contiguous() or t.dtype != torch.float32:
+                raise ValueError("ViterbiNet parameters must be contiguous fp32")
+        loss = torch.empty(n, dtype=torch.float32, device=dev) if return_loss else None
+        with torch.cuda.device(dev):
+            rc = _lib.load().mvn_vnet_maml_train_f32(_lib.ptr(rx), _lib.ptr(labels), T, _lib.ptr(sup), W, _lib.ptr(qry), n,
+                                                     *[_lib.ptr(t.data) for t in p], _lib.ptr(self.exp_avg),
+                                                     _lib.ptr(self.exp_avg_sq), self.step, meta_lr, 1 if MAML else 0,
+                                                     self.lr, self.betas[0], self.betas[1], self.eps, _lib.ptr(loss),
+                                                     p[5].numel(), _lib.current_stream(dev))
+        _lib.check(rc, "mvn_vnet_maml_train_f32")
+        self.step += n
+        return loss
+
     def select_batches(self, T: int, iterations: int) -> torch.Tensor:
         """`iterations` minibatches drawn like select_batch (trainer.py:542): torch.multinomial with weights
         arange(T) (sample 0 is never drawn), without replacement, all iterations in one call."""

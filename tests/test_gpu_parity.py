@@ -863,6 +863,38 @@ def test_graphed_meta_step_matches_eager(golden, dev, MAML):
     assert torch.allclose(trs[0].exp_avg, trs[1].exp_avg, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("MAML,W", [(True, 1), (False, 1), (True, 2)])
+def test_maml_kernel_vs_torch_double_backward(golden, dev, MAML, W):
+    """mvn_vnet_maml_train_f32 (inner SGD step, query gradient, exact Hessian-vector product by the R-operator, Adam; all
+    steps in one launch) against meta.meta_train_loop = torch autograd with create_graph=True + torch-style Adam on the
+    same words.  Tolerance as for the training kernel: |dw| <= 2e-5 + 1e-3 |w|, query loss rtol 2e-4 (reduction order and
+    1-ulp sqrt / rcp in Adam differ from torch's)."""
+    g7 = golden("g7_by_word")
+    w = [g7[f"w{i}"] for i in range(6)]
+    T, L, S, n_steps = 136, 4, 16, 6
+    gen = torch.Generator(device=dev).manual_seed(5 + W)
+    rxw = torch.randn(7, T, generator=gen, device=dev)
+    txw = torch.randint(0, 2, (7, T), generator=gen, device=dev).float()
+    dets = [_vnet_with(w, S, T, dev) for _ in range(2)]
+    trs = [mvn.OnlineTrainer(d, L) for d in dets]
+    for tr in trs:
+        tr.step = 4
+    trs[0].exp_avg.normal_(0, 1e-3, generator=gen)
+    trs[0].exp_avg_sq.uniform_(1e-7, 1e-5, generator=gen)
+    trs[1].exp_avg.copy_(trs[0].exp_avg)
+    trs[1].exp_avg_sq.copy_(trs[0].exp_avg_sq)
+    meta = mvn.META_VNETDetector(S, {"train": T, "val": T})
+    sup = torch.stack([torch.arange(k - W, k, device=dev) for k in range(n_steps)])  # step 0 uses negative indices
+    qry = torch.arange(n_steps, device=dev)
+    ref_loss = [float(mvn.meta_train_loop(dets[0], meta, trs[0], rxw, txw, sup[k], qry[k:k + 1], 0.1, MAML)) for k in range(n_steps)]
+    loss = trs[1].maml_training(rxw, txw, sup, qry, 0.1, MAML, return_loss=True)
+    assert trs[1].step == trs[0].step == 4 + n_steps
+    assert np.allclose(_np(loss), np.array(ref_loss), rtol=2e-4, atol=1e-6)
+    for a, b in zip(dets[1].parameters(), dets[0].parameters()):
+        assert bool((torch.abs(a - b) <= 2e-5 + 1e-3 * torch.abs(b)).all())
+    assert torch.allclose(trs[1].exp_avg, trs[0].exp_avg, rtol=1e-3, atol=1e-6)
+
+
 def test_nonfinite_samples_like_reference(oracle, dev, monkeypatch):
     """NaN / +-inf received samples: the reference turns every branch cost of that symbol into NaN (ViterbiNet: the MLP
     propagates it; VA: (NaN - prior)^2), after which torch.min/argmin leave all metrics NaN and every later decision 0.

@@ -43,19 +43,22 @@ for name, kw in (("joint (no updates)", {}), ("self-supervised, 200 it/block", {
     print(f"eval_by_word {name}: {dt*1e3:.1f} ms for {N} blocks = {dt/N*1e6:.0f} us/block, mean ser {ser.mean():.4f}")
 # BASELINE configs[4]: Meta-ViterbiNet online evaluation with the reference's defaults (every 5 blocks: 20 x 10 MAML
 # meta-steps through torch autograd; after every qualifying block: 200 full-word iterations of the HIP training kernel)
-det = make()
-meta = mvn.META_VNETDetector(16, {"train": 136, "val": 136})
-tr = mvn.OnlineTrainer(det, L)
 NM = 60
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-ser = mvn.eval_by_word(det, msg[:NM], y[:NM], snr, 0.2, nsym, 25, self_supervised=True, online_trainer=tr,
-                       self_supervised_iterations=200, online_meta=True, meta_detector=meta, meta_train_iterations=20,
-                       meta_j_num=10, meta_subframes=5, meta_style_online_training=True)
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-print(f"eval_by_word online meta (MAML in torch autograd + HIP training kernel): {dt*1e3:.0f} ms for {NM} blocks = "
-      f"{dt/NM*1e3:.1f} ms/block, mean ser {ser.mean():.4f}", flush=True)
+for name, kw in (("HIP meta-learning kernel", {}), ("torch autograd replayed from a hipGraph", {"hip_meta": False}),
+                 ("eager torch autograd", {"hip_meta": False, "graphed_meta": False})):
+    det = make()
+    meta = mvn.META_VNETDetector(16, {"train": 136, "val": 136})
+    tr = mvn.OnlineTrainer(det, L)
+    torch.manual_seed(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ser = mvn.eval_by_word(det, msg[:NM], y[:NM], snr, 0.2, nsym, 25, self_supervised=True, online_trainer=tr,
+                           self_supervised_iterations=200, online_meta=True, meta_detector=meta, meta_train_iterations=20,
+                           meta_j_num=10, meta_subframes=5, meta_style_online_training=True, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"eval_by_word online meta, MAML steps by {name}: {dt*1e3:.0f} ms for {NM} blocks = {dt/NM*1e3:.1f} ms/block, "
+          f"mean ser {ser.mean():.4f}", flush=True)
 det = make()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
