@@ -14,6 +14,7 @@
 // and, in the .inc files included below (each starts with its own description):
 //   vnet16_fused4.inc / vnet16_fused.inc   fused ViterbiNet detector at 16 states (MLP on MFMA + in-place DPP sweep)
 //   sweep16_rows / _lds / _quad.inc        16-state sweeps over materialised costs (register prefetch, LDS-DMA)
+//   sweep_inplace.inc                      the same sweep for any other S >= 4 (in-place recurrence + LDS-DMA)
 //   va16_quad.inc, va_inplace.inc          fused classical Viterbi (16 states; any S >= 4)
 //   rs_codec.inc                           Reed-Solomon encode/decode
 //   online_train.inc, maml_train.inc       one-launch online training and MAML meta-learning steps
@@ -389,6 +390,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 #include "sweep16_quad.inc"
 #include "va16_quad.inc"
 #include "va_inplace.inc"
+#include "sweep_inplace.inc"
 #include "rs_codec.inc"
 #include "online_train.inc"
 #include "maml_train.inc"
@@ -609,6 +611,15 @@ int dispatch_sweep(const float *src, int64_t src_ld, const float *priors, int64_
         const char *e = getenv("MVN_VA_INPLACE");
         if (S >= 4 && !generic_sweep_forced() && (S != 16 || (e && e[0] == '1')))
             return launch_va_inplace(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, S, st);
+    }
+    if constexpr (MODE != MODE_VA) {
+        // materialised costs at S != 16: in-place recurrence + LDS-DMA streaming for any S >= 4 (MVN_SWEEP_INPLACE=1 sends
+        // S = 16 here too, for cross-checks); unaligned buffers and S = 2 fall through to the generic kernel
+        const char *e = getenv("MVN_SWEEP_INPLACE");
+        if (S >= 4 && !generic_sweep_forced() && (S != 16 || (e && e[0] == '1'))) {
+            const int rc = launch_sweep_inplace<MODE>(src, dec, dec_ld, final_metric, B, T, S, st);
+            if (rc != -1) return rc;
+        }
     }
     if (S == 16 && !generic_sweep_forced()) {
         if constexpr (MODE != MODE_VA) {  // materialised costs: stream them through LDS in 1-KB pieces

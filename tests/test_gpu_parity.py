@@ -153,16 +153,27 @@ def _rand_weights(S, rng, scale=1.0):
 
 
 @pytest.mark.parametrize("S", [2, 4, 8, 16, 32, 64, 128, 256])
-@pytest.mark.parametrize("B,T", [(1, 1), (3, 7), (5, 64), (67, 129), (130, 33)])
-def test_sweep_vs_oracle(oracle, dev, S, B, T):
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 7), (5, 64), (67, 129), (130, 33), (70, 100)])
+def test_sweep_vs_oracle(oracle, dev, monkeypatch, S, B, T):
+    """mvn_acs_sweep_f32 for every S: the default kernel (in-place + LDS-DMA streaming for S >= 4; the 16-state kernels at
+    S = 16), the in-place template forced at S = 16 too, the generic LDS-exchange kernel, and a decision buffer whose
+    row stride is not a multiple of 4 (scalar-store fallbacks)."""
     rng = np.random.RandomState(S * 1000 + B * 10 + T)
     cost = rng.normal(0, 2, (B, T, S)).astype(np.float32)
     if B > 2:
         cost[1] = 0.25  # all-equal costs: every comparison ties
         cost[2, :, ::2] = cost[2, :, 1::2]
-    dec, fm = mvn.acs_sweep(torch.tensor(cost, device=dev), return_final=True)
     rdec, rfm = oracle.acs_sweep(cost)
-    assert np.array_equal(_np(dec), rdec) and np.array_equal(_np(fm), rfm)
+    ct = torch.tensor(cost, device=dev)
+    lib, st = mvn._lib.load(), mvn._lib.current_stream(dev)
+    for generic, inplace, ld in (("0", "0", T), ("0", "1", T + (-T) % 4), ("1", "0", T), ("0", "0", T + 1)):
+        monkeypatch.setenv("MVN_GENERIC_SWEEP", generic)
+        monkeypatch.setenv("MVN_SWEEP_INPLACE", inplace)
+        dec = torch.full((B, ld), 7.0, device=dev)
+        fm = torch.empty(B, S, device=dev)
+        assert lib.mvn_acs_sweep_f32(mvn._lib.ptr(ct), mvn._lib.ptr(dec), ld, mvn._lib.ptr(fm), B, T, S, st) == 0
+        assert np.array_equal(_np(dec[:, :T]), rdec) and np.array_equal(_np(fm), rfm), (generic, inplace, ld)
+        assert bool((dec[:, T:] == 7.0).all())
 
 
 @pytest.mark.parametrize("S", [2, 4, 8, 16, 32, 64, 128, 256])

@@ -25,7 +25,10 @@ for B in [int(a) for a in args] or [10000, 40000]:
     cost = torch.randn(B, T, S, device=dev)
     ref = None
     for v in variants:
-        if v:
+        os.environ.pop("MVN_SWEEP_INPLACE", None)
+        if v == "inplace":
+            os.environ["MVN_SWEEP_INPLACE"] = "1"
+        elif v:
             os.environ["MVN_SWEEP16"] = v
         dec = torch.zeros(B, T, device=dev)
 
