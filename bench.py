@@ -108,6 +108,49 @@ def cpu_baseline_torch_path(weights_np, seed):
                       f"{blocks} blocks x {T} symbols, {dt:.1f} s"}
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without an external launcher: start the N ranks ourselves (one process per GPU),
+    BEFORE anything touches the GPU in this process.  The parent never initialises HIP and never exec()s: it waits
+    for its children, relays their output (rank 0 prints the JSON line) and exits non-zero if any rank failed."""
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:  # one rank died: the others would wait in a collective for ever
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                    for q in pending:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:  # exact PIDs we started, nothing else
+            if p.poll() is None:
+                p.kill()
+            p.wait()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,15 +158,24 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=10000, help="blocks per GPU (BASELINE configs[1]: 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config entries (BASELINE configs[0],[2],[3],[4])")
     ap.add_argument("--skip-fused-count", action="store_true", help="(profiling) keep every fused-kernel dispatch decode-only: no fused-count timing, no FER curve")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     ndev = torch.cuda.device_count()
-    local_dev = local_rank % max(ndev, 1)  # (ranks > devices only happens in the gloo rehearsal below)
+    if ndev == 0:
+        sys.exit("bench.py: no GPU visible; the hot path has no CPU fallback")
+    if world > ndev and os.environ.get("MVN_BENCH_BACKEND", "nccl") == "nccl":
+        sys.exit(f"bench.py: {world} ranks but {ndev} GPU(s): one process per GPU is the contract "
+                 "(MVN_BENCH_BACKEND=gloo rehearses the control flow with ranks sharing a GPU)")
+    local_dev = local_rank % ndev  # (ranks > devices only happens in the gloo rehearsal)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     # MVN_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks;
