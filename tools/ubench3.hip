@@ -23,11 +23,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define REP16(x) REP8(x) REP8(x)
 
 enum Role { IDLE = 0, R_MFMA, R_SIGMOID, R_FMAC, R_INT, R_RCP, R_MOV, R_DPP, R_PERMSWAP, R_FMA3, R_FMAAK, R_MULLIT, R_LSHLADD,
-            R_FMACLIT, R_LDSREAD, R_SIGMOID2, R_MFMA4x4, N_ROLES };
+            R_FMACLIT, R_LDSREAD, R_SIGMOID2, R_MFMA4x4, R_K0, R_K1, R_K2, R_MFMA_DIFF, R_K3, R_K4, N_ROLES };
 static const char* kRoleName[N_ROLES] = {"-", "M", "Vsig", "Vfmac", "Vint", "Vrcp", "Vmov", "Vdpp", "Vswap", "Vfma3", "Vfmaak",
-                                         "Vmullit", "Vlshladd", "Vfmaclit", "Vlds", "Vsig2", "M4x4"};
+                                         "Vmullit", "Vlshladd", "Vfmaclit", "Vlds", "Vsig2", "M4x4", "K0", "K1", "K2", "Mdiff", "K3bar", "K4bar2"};
 // wave-instructions per loop iteration of each role (for cycles/instruction)
-static const int kOpsPerIter[N_ROLES] = {0, 16, 80, 64, 64, 32, 64, 64, 32, 64, 64, 64, 64, 64, 32, 160, 32};
+static const int kOpsPerIter[N_ROLES] = {0, 16, 80, 64, 64, 32, 64, 64, 32, 64, 64, 64, 64, 64, 32, 160, 32, 92, 92, 92, 16, 92, 184};
+
+#define SIG1(D, Y)                                                                                                     \
+    "v_fma_f32 %[t0], " Y ", %[a], %[b]\n v_mul_f32 %[t1], 0x3fb8aa3b, %[t0]\n v_add_f32 %[t1], 0x4b400000, %[t1]\n"      \
+    "v_add_f32 %[t2], 0xcb400000, %[t1]\n v_fmac_f32 %[t0], 0xbf317200, %[t2]\n v_fmac_f32 %[t0], 0xb5bfbe8e, %[t2]\n"    \
+    "v_fmamk_f32 %[t2], %[t0], 0x39502bda, %[c]\n v_fmaak_f32 %[t2], %[t2], %[t0], 0x3c0888a6\n"                          \
+    "v_fmaak_f32 %[t2], %[t2], %[t0], 0x3d2aaa7a\n v_fmaak_f32 %[t2], %[t2], %[t0], 0x3e2aaaab\n"                         \
+    "v_mul_f32 %[t3], %[t0], %[t0]\n v_fma_f32 %[t2], %[t2], %[t0], 0.5\n v_fmac_f32 %[t0], %[t3], %[t2]\n"               \
+    "v_add_f32 %[t0], 1.0, %[t0]\n v_lshl_add_u32 %[t0], %[t1], 23, %[t0]\n v_add_f32 %[t0], 1.0, %[t0]\n"               \
+    "v_rcp_f32 " D ", %[t0]\n s_nop 0\n v_fma_f32 %[t0], -%[t0], " D ", 1.0\n v_fmac_f32 " D ", %[t0], " D "\n"
 
 struct Stamp { unsigned long long t0, t1, r0, r1; unsigned hwid, role; };
 
@@ -67,14 +76,6 @@ __global__ __launch_bounds__(1024) void kroles(Stamp* out, float* sink, const in
         // the fused kernel's fast sigmoid, instruction for instruction (20 per activation; a dependent chain).
         // R_SIGMOID: 4 activations one after the other (like the kernel: sched_barrier keeps them apart) = 80 instr/iter
         // R_SIGMOID2: two chains interleaved instruction by instruction, 8 activations = 160 instr/iter
-#define SIG1(D, Y)                                                                                                     \
-    "v_fma_f32 %[t0], " Y ", %[a], %[b]\n v_mul_f32 %[t1], 0x3fb8aa3b, %[t0]\n v_add_f32 %[t1], 0x4b400000, %[t1]\n"      \
-    "v_add_f32 %[t2], 0xcb400000, %[t1]\n v_fmac_f32 %[t0], 0xbf317200, %[t2]\n v_fmac_f32 %[t0], 0xb5bfbe8e, %[t2]\n"    \
-    "v_fmamk_f32 %[t2], %[t0], 0x39502bda, %[c]\n v_fmaak_f32 %[t2], %[t2], %[t0], 0x3c0888a6\n"                          \
-    "v_fmaak_f32 %[t2], %[t2], %[t0], 0x3d2aaa7a\n v_fmaak_f32 %[t2], %[t2], %[t0], 0x3e2aaaab\n"                         \
-    "v_mul_f32 %[t3], %[t0], %[t0]\n v_fma_f32 %[t2], %[t2], %[t0], 0.5\n v_fmac_f32 %[t0], %[t3], %[t2]\n"               \
-    "v_add_f32 %[t0], 1.0, %[t0]\n v_lshl_add_u32 %[t0], %[t1], 23, %[t0]\n v_add_f32 %[t0], 1.0, %[t0]\n"               \
-    "v_rcp_f32 " D ", %[t0]\n s_nop 0\n v_fma_f32 %[t0], -%[t0], " D ", 1.0\n v_fmac_f32 " D ", %[t0], " D "\n"
         float t0_, t1_, t2_, t3_, u0_, u1_, u2_, u3_;
         if (role == R_SIGMOID) {
             for (int it = 0; it < n; ++it) {
@@ -112,6 +113,55 @@ __global__ __launch_bounds__(1024) void kroles(Stamp* out, float* sink, const in
                              : [y0] "v"(x0), [y1] "v"(x1), [y2] "v"(x2), [y3] "v"(x3), [a] "v"(a), [b] "v"(b), [c] "v"(c100));
             }
         }
+    } else if (role == R_MFMA_DIFF) {  // like M, but every MFMA has its own A and B registers
+        for (int it = 0; it < n; ++it) {
+            REP2(c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, x1, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x2, x3, c1, 0, 0, 0);
+                 c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x4, x5, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(x6, x7, c3, 0, 0, 0);
+                 c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, x2, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x3, x4, c1, 0, 0, 0);
+                 c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x5, x6, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(x7, x0, c3, 0, 0, 0);)
+        }
+    } else if (role == R_K0 || role == R_K1 || role == R_K2 || role == R_K3 || role == R_K4) {
+        // the fused kernel's k-step pattern: 4 x (sigmoid chain, 3 MFMAs).  K0: the MFMAs' B operand is the sigmoid just
+        // computed (as in the kernel); K1: fixed operands (no VALU -> MFMA dependence); K2: 4 sigmoids, then 12 MFMAs.
+        f32x4 d0 = c0, d1 = c0, d2 = c0, d3 = c0, e0 = c0, e1 = c0, e2 = c0, e3 = c0;
+        float t0_, t1_, t2_, t3_;
+        for (int it = 0; it < n; ++it) {
+#define KSIG(D, Y) asm volatile(SIG1("%[d0]", "%[y0]") : [d0] "=&v"(D), [t0] "=&v"(t0_), [t1] "=&v"(t1_), [t2] "=&v"(t2_), [t3] "=&v"(t3_) \
+                                : [y0] "v"(Y), [a] "v"(a), [b] "v"(b), [c] "v"(c100))
+#define KMF(A0, A1, A2, Bv, C0, C1, C2) C0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0, Bv, C0, 0, 0, 0); \
+            C1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1, Bv, C1, 0, 0, 0); C2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A2, Bv, C2, 0, 0, 0)
+            if (role == R_K0) {
+                KSIG(x4, x0); __builtin_amdgcn_sched_barrier(0); KMF(x1, x2, x3, x4, c0, c1, c2); __builtin_amdgcn_sched_barrier(0);
+                KSIG(x5, x1); __builtin_amdgcn_sched_barrier(0); KMF(x1, x2, x3, x5, c3, d0, d1); __builtin_amdgcn_sched_barrier(0);
+                KSIG(x6, x2); __builtin_amdgcn_sched_barrier(0); KMF(x1, x2, x3, x6, d2, d3, e0); __builtin_amdgcn_sched_barrier(0);
+                KSIG(x7, x3); __builtin_amdgcn_sched_barrier(0); KMF(x1, x2, x3, x7, e1, e2, e3); __builtin_amdgcn_sched_barrier(0);
+            } else if (role == R_K1) {
+                KSIG(x4, x0); __builtin_amdgcn_sched_barrier(0); KMF(x1, x2, x3, x0, c0, c1, c2); __builtin_amdgcn_sched_barrier(0);
+                KSIG(x5, x1); __builtin_amdgcn_sched_barrier(0); KMF(x1, x2, x3, x0, c3, d0, d1); __builtin_amdgcn_sched_barrier(0);
+                KSIG(x6, x2); __builtin_amdgcn_sched_barrier(0); KMF(x1, x2, x3, x0, d2, d3, e0); __builtin_amdgcn_sched_barrier(0);
+                KSIG(x7, x3); __builtin_amdgcn_sched_barrier(0); KMF(x1, x2, x3, x0, e1, e2, e3); __builtin_amdgcn_sched_barrier(0);
+            } else if (role == R_K3) {  // phases separated by workgroup barriers (every wave of the CU runs this role)
+                KSIG(x4, x0); KSIG(x5, x1); KSIG(x6, x2); KSIG(x7, x3); __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+                KMF(x1, x2, x3, x4, c0, c1, c2); KMF(x1, x2, x3, x5, c3, d0, d1); KMF(x1, x2, x3, x6, d2, d3, e0);
+                KMF(x1, x2, x3, x7, e1, e2, e3); __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+            } else if (role == R_K4) {  // two k-steps per phase: 8 sigmoids | barrier | 24 MFMAs | barrier
+                float z0, z1, z2, z3;
+                KSIG(x4, x0); KSIG(x5, x1); KSIG(x6, x2); KSIG(x7, x3); KSIG(z0, x3); KSIG(z1, x2); KSIG(z2, x1); KSIG(z3, x0);
+                __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+                KMF(x1, x2, x3, x4, c0, c1, c2); KMF(x1, x2, x3, x5, c3, d0, d1); KMF(x1, x2, x3, x6, d2, d3, e0);
+                KMF(x1, x2, x3, x7, e1, e2, e3);
+                KMF(x1, x2, x3, z0, c0, c1, c2); KMF(x1, x2, x3, z1, c3, d0, d1); KMF(x1, x2, x3, z2, d2, d3, e0);
+                KMF(x1, x2, x3, z3, e1, e2, e3); __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+            } else {
+                KSIG(x4, x0); KSIG(x5, x1); KSIG(x6, x2); KSIG(x7, x3); __builtin_amdgcn_sched_barrier(0);
+                KMF(x1, x2, x3, x4, c0, c1, c2); KMF(x1, x2, x3, x5, c3, d0, d1); KMF(x1, x2, x3, x6, d2, d3, e0);
+                KMF(x1, x2, x3, x7, e1, e2, e3); __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        c0 += d0 + d1 + d2 + d3 + e0 + e1 + e2 + e3;
     } else if (role == R_FMAC) {  // VOP2, all VGPR, 8 independent chains
         for (int it = 0; it < n; ++it) {
             REP8(asm volatile("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n"
@@ -270,8 +320,9 @@ int main(int argc, char** argv) {
     iters[R_MFMA] = mf; iters[R_MFMA4x4] = 8000; iters[R_SIGMOID] = 5000; iters[R_SIGMOID2] = 2500; iters[R_RCP] = 8000;
     iters[R_PERMSWAP] = 8000; iters[R_LDSREAD] = 4000;
 
+    if (argc <= 1 || strcmp(argv[1], "k"))
     printf("# part 1: issue cost per instruction form (one role on 1, 2, 4 waves of every SIMD; cycles per wave-instruction per SIMD)\n");
-    for (int role = R_MFMA; role < N_ROLES; ++role) {
+    for (int role = R_MFMA; role < R_K0 && (argc <= 1 || strcmp(argv[1], "k")); ++role) {
         for (int nw : {1, 2, 4}) {
             int roles[4] = {IDLE, IDLE, IDLE, IDLE};
             for (int k = 0; k < nw; ++k) roles[k] = role;
@@ -282,6 +333,20 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
     }
+    printf("# part 3: the kernel's k-step pattern (4 x [20-instruction sigmoid chain + 3 MFMA]); nominal = 80 x VALU cost + 12 x 32\n");
+    iters[R_K0] = iters[R_K1] = iters[R_K2] = 3000; iters[R_MFMA_DIFF] = 4000;
+    iters[R_K3] = 3000; iters[R_K4] = 1500;
+    for (int role : {R_K0, R_K2, R_K3, R_K4}) {
+        for (int nw : {4}) {
+            int roles[4] = {IDLE, IDLE, IDLE, IDLE};
+            for (int k = 0; k < nw; ++k) roles[k] = role;
+            Result r = run(roles, iters, 11);
+            printf("%-6s waves/SIMD=%d  span=%9.0f cyc  per k-step per wave-slot: %7.1f cyc  (%.2f GHz)\n", kRoleName[role], nw, r.span_cyc,
+                   r.span_cyc / iters[role] / nw / (role == R_K4 ? 2 : 1), r.ghz);
+            fflush(stdout);
+        }
+    }
+    if (argc > 1 && !strcmp(argv[1], "k")) return 0;
     printf("# part 2: two MFMA waves beside two VALU waves on every SIMD.  additive = sum of the two single-role spans, overlap = max\n");
     const int vroles[] = {R_SIGMOID, R_SIGMOID2, R_FMAC, R_FMA3, R_INT, R_RCP, R_MOV, R_DPP, R_PERMSWAP, R_LDSREAD, R_MFMA4x4};
     {
