@@ -12,7 +12,7 @@
 //                          exact k-ordered fmaf chains == torch-CPU sgemm result order.
 //   count_errors_kernel    metrics.py:7-17 as int64 counters.
 // and, in the .inc files included below (each starts with its own description):
-//   vnet16_fused4.inc / vnet16_fused.inc   fused ViterbiNet detector at 16 states (MLP on MFMA + in-place DPP sweep)
+//   vnet16_fusedn.inc / vnet16_fused.inc   fused ViterbiNet detector at 16 states (MLP on MFMA + in-place DPP sweep)
 //   sweep16_rows / _lds / _quad.inc        16-state sweeps over materialised costs (register prefetch, LDS-DMA)
 //   sweep_inplace.inc                      the same sweep for any other S >= 4 (in-place recurrence + LDS-DMA)
 //   va16_quad.inc, va_inplace.inc          fused classical Viterbi (16 states; any S >= 4)
@@ -29,8 +29,10 @@
 
 namespace {
 
-constexpr bool kFusedLdsDefault = true;
-constexpr bool kFused4Default = true;
+#ifndef MVN_FUSEDN_DEFAULT
+#define MVN_FUSEDN_DEFAULT 2
+#endif
+constexpr int kFusedNDefault = MVN_FUSEDN_DEFAULT;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -384,7 +386,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 }
 
 #include "vnet16_fused.inc"
-#include "vnet16_fused4.inc"
+#include "vnet16_fusedn.inc"
 #include "sweep16_rows.inc"
 #include "sweep16_lds.inc"
 #include "sweep16_quad.inc"
@@ -495,47 +497,11 @@ bool unfused_forced() {
     return e && e[0] == '1';
 }
 
-// MVN_FUSED4=0/1 selects the 16-symbol-tile kernel (vnet16_fused.inc) or the 64-symbol super-tile kernel
-// (vnet16_fused4.inc).
-bool fused4_enabled() {
-    const char *e = getenv("MVN_FUSED4");
-    return e ? e[0] == '1' : kFused4Default;
-}
-
-// MVN_FUSED_LDSW=0/1 selects the register- or LDS-resident weight variant of the fused kernel.
-bool fused_lds_weights() {
-    const char *e = getenv("MVN_FUSED_LDSW");
-    return e ? e[0] == '1' : kFusedLdsDefault;
-}
-
-// Residency choice for the LDS-weights fused kernel.  One wave owns one block for all T symbols, so the
-// kernel's makespan is ceil(B / resident_waves) wave lifetimes: pick the workgroups/CU (3 or 4, i.e. 12 or 16
-// waves/CU; 4 is the VGPR limit) whose slot count divides B best, and enforce it by padding the launch's dynamic LDS.
-// MVN_FUSED_WGS_PER_CU=n overrides.
-unsigned fused_dynamic_lds_pad(int64_t B) {
-    constexpr int kStaticLds = 29728;      // ldsA2 + ldsWB + ldsB3w (see -Rpass-analysis)
-    constexpr int kLdsPerCu = 160 * 1024;  // gfx950
-    int best = 4;
-    const char *e = getenv("MVN_FUSED_WGS_PER_CU");
-    if (e && e[0] >= '1' && e[0] <= '4') {
-        best = e[0] - '0';
-    } else {
-        double best_score = 0.0;
-        for (int w = 3; w <= 4; ++w) {
-            const double slots = 256.0 * w * kFusedWavesLds;
-            const double rounds = (double)B / slots;
-            const double eff = rounds / (double)(int64_t)(rounds + 0.999999);
-            const double rate = w == 3 ? 0.89 : 1.0;  // measured relative SIMD throughput (tools/ab_fused.py)
-            if (eff * rate > best_score) {
-                best_score = eff * rate;
-                best = w;
-            }
-        }
-    }
-    if (best >= 4) return 0;
-    const int per_wg = kLdsPerCu / best;        // at most `best` workgroups fit
-    const int need = per_wg - kStaticLds - 512;  // keep (best+1) from fitting
-    return need > 0 ? (unsigned)need : 0;
+// MVN_FUSEDN=2|4 pins the tiles per super-tile of the fused kernel (vnet16_fusedn.inc); default 2 (5 waves/SIMD).
+int fusedn_tiles() {
+    const char *e = getenv("MVN_FUSEDN");
+    if (e && (e[0] == '2' || e[0] == '4')) return e[0] - '0';
+    return kFusedNDefault;
 }
 
 // counters[1] += K * (#counted rows), counters[3] += #counted rows  (rows with mask != 0, or all B when mask is NULL)
@@ -562,30 +528,21 @@ int launch_vnet16_fused(const float *y, int64_t y_ld, const float *W1, const flo
                         const float *W3, const float *b3, float *dec, int64_t dec_ld, float *logits_out,
                         float *final_metric, int64_t B, int T, const float *tx, int64_t tx_ld, int K,
                         const unsigned char *row_mask, unsigned long long *counters, hipStream_t st) {
-    if (fused4_enabled()) {  // 64-symbol super-tiles: units 48,49 on v_mfma_f32_4x4x1 instead of a padded row tile
-        const unsigned grid4 = (unsigned)((B + kFused4Waves - 1) / kFused4Waves);
-        if (logits_out)
-            hipLaunchKernelGGL((vnet16_fused4_kernel<true>), dim3(grid4), dim3(64 * kFused4Waves), 0, st, y, y_ld, W1, b1,
-                               W2, b2, W3, b3, dec, dec_ld, logits_out, final_metric, B, T, tx, tx_ld, K, row_mask, counters);
-        else
-            hipLaunchKernelGGL((vnet16_fused4_kernel<false>), dim3(grid4), dim3(64 * kFused4Waves), 0, st, y, y_ld, W1, b1,
-                               W2, b2, W3, b3, dec, dec_ld, logits_out, final_metric, B, T, tx, tx_ld, K, row_mask, counters);
-        if (tx) hipLaunchKernelGGL(count_totals_kernel, dim3(1), dim3(1024), 0, st, row_mask, B, K, counters);
-        return (int)hipGetLastError();
-    }
-    const bool ldsw = fused_lds_weights();
-    const int wpb = ldsw ? kFusedWavesLds : kFusedWaves;
-    const unsigned grid = (unsigned)((B + wpb - 1) / wpb);
-    const unsigned dyn_lds = ldsw ? fused_dynamic_lds_pad(B) : 0;
-#define MVN_FUSED_LAUNCH(WL, LW)                                                                                       \
-    hipLaunchKernelGGL((vnet16_fused_kernel<WL, LW>), dim3(grid), dim3(64 * wpb), dyn_lds, st, y, y_ld, W1, b1, W2, b2, \
-                       W3, b3, dec, dec_ld, logits_out, final_metric, B, T, tx, tx_ld, K, row_mask, counters)
-    if (logits_out) {
-        if (ldsw) MVN_FUSED_LAUNCH(true, true); else MVN_FUSED_LAUNCH(true, false);
+    const int nt = fusedn_tiles();  // NT = 2 runs 5 waves/SIMD (default); NT = 4 is the 64-symbol form, kept as a cross-check
+    const unsigned gridn = (unsigned)((B + kFusedNWaves - 1) / kFusedNWaves);
+    // blocks of the last round of wave slots (256 CUs x workgroups per CU x 4 waves): see the kernel's priority note
+    const char *fe = getenv("MVN_FUSEDN_FINAL");
+    const int64_t final_blocks = fe ? atoll(fe) : 256 * (int64_t)(nt == 2 ? MVN_FN_WGS : 4) * kFusedNWaves;
+#define MVN_FUSEDN_LAUNCH(WL, NT)                                                                                      \
+    hipLaunchKernelGGL((vnet16_fusedn_kernel<WL, NT>), dim3(gridn), dim3(64 * kFusedNWaves), 0, st, y, y_ld, W1, b1, W2, b2, \
+                       W3, b3, dec, dec_ld, logits_out, final_metric, B, T, tx, tx_ld, K, row_mask, counters, final_blocks)
+    if (nt == 2) {
+        if (logits_out) MVN_FUSEDN_LAUNCH(true, 2); else MVN_FUSEDN_LAUNCH(false, 2);
     } else {
-        if (ldsw) MVN_FUSED_LAUNCH(false, true); else MVN_FUSED_LAUNCH(false, false);
+        if (logits_out) MVN_FUSEDN_LAUNCH(true, 4); else MVN_FUSEDN_LAUNCH(false, 4);
     }
-#undef MVN_FUSED_LAUNCH
+#undef MVN_FUSEDN_LAUNCH
+    if (tx) hipLaunchKernelGGL(count_totals_kernel, dim3(1), dim3(1024), 0, st, row_mask, B, K, counters);
     return (int)hipGetLastError();
 }
 

@@ -215,7 +215,8 @@ def test_vnet_vs_oracle(oracle, dev, S, B, T):
     assert np.array_equal(_np(det.logits(yt)), rlg)
 
 
-@pytest.mark.parametrize("B,T", [(4, 16), (5, 17), (3, 63), (2, 64), (3, 65), (300, 136), (257, 1000), (64, 31), (2, 1)])
+@pytest.mark.parametrize("B,T", [(4, 16), (5, 17), (3, 63), (2, 64), (3, 65), (300, 136), (257, 1000), (64, 31), (2, 1),
+                                 (3, 32), (5, 33), (2, 47), (3, 48), (5300, 40)])
 def test_vnet16_fused_and_unfused_paths(oracle, dev, monkeypatch, B, T):
     """S=16 runs the fused single-kernel path by default; MVN_UNFUSED=1 forces MLP -> logits -> sweep.
     Both must equal the oracle bit for bit (decisions, logits, final path metrics), including tiles
@@ -230,10 +231,9 @@ def test_vnet16_fused_and_unfused_paths(oracle, dev, monkeypatch, B, T):
     rdec, rlg, rfm = oracle.vnet_decode(y, w, want_logits=True, want_final=True)
     lib = mvn._lib.load()
     ws = torch.empty(B * T * S * 4, dtype=torch.uint8, device=dev)
-    for unfused, ldsw, f4 in (("0", "0", "0"), ("0", "1", "0"), ("0", "1", "1"), ("1", "0", "0")):
+    for unfused, nt in (("0", "2"), ("0", "4"), ("1", "2")):
         monkeypatch.setenv("MVN_UNFUSED", unfused)
-        monkeypatch.setenv("MVN_FUSED_LDSW", ldsw)  # register- vs LDS-resident weights in the fused kernel
-        monkeypatch.setenv("MVN_FUSED4", f4)  # 16-symbol tiles vs 64-symbol super-tiles (4x4x1 MFMA for units 48,49)
+        monkeypatch.setenv("MVN_FUSEDN", nt)  # 32-symbol (5 waves/SIMD, default) or 64-symbol super-tiles of the fused kernel
         for want_logits in (False, True):
             dec = torch.zeros_like(yt)
             fm = torch.empty(B, S, device=dev)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Edits of the compiler's assembly for vnet16_fused4_kernel<false> (timing experiments only).
+"""Edits of the compiler's assembly for vnet16_fusedn_kernel<false, 2> (timing experiments only).
    edit.py in.s out.s nonop        : drop every s_nop inside the two depth-2 loops (the k-loops)  [results may be wrong]
    edit.py in.s out.s nonop_all    : drop every s_nop of the kernel
    edit.py in.s out.s dup:REGEX    : issue every matching instruction of the k-loops twice (marginal cost in situ)
@@ -9,7 +9,7 @@ import re
 import sys
 src, dst, what = sys.argv[1:4]
 L = open(src).read().split("\n")
-beg = next(i for i, l in enumerate(L) if l.startswith("_ZN12_GLOBAL__N_120vnet16_fused4_kernelILb0EE"))
+beg = next(i for i, l in enumerate(L) if l.startswith("_ZN12_GLOBAL__N_120vnet16_fusedn_kernelILb0ELi2EE"))
 end = next(i for i in range(beg, len(L)) if L[i].startswith(".Lfunc_end"))
 out, depth2, n = [], False, 0
 for i, l in enumerate(L):

@@ -1,8 +1,8 @@
-// Assembly-level tuning harness (not shipped): loads a gfx950 code object holding vnet16_fused4_kernel<false>
+// Assembly-level tuning harness (not shipped): loads a gfx950 code object holding vnet16_fusedn_kernel<false, 2>
 // (hipModuleLoad), runs it on BASELINE configs[1]'s shape and prints the median launch time; with a second code
 // object it also checks that both produce identical decisions (so an edited instruction stream can be validated
 // against the compiler's).
-//   f4_asm_bench edited.co [reference.co] [B]
+//   fused_asm_bench edited.co [reference.co] [B]
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -11,11 +11,11 @@
 #include <random>
 #include <vector>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
-static const char* kSym = "_ZN12_GLOBAL__N_120vnet16_fused4_kernelILb0EEEvPKflS2_S2_S2_S2_S2_S2_PflS3_S3_liS2_liPKhPy";
+static const char* kSym = "_ZN12_GLOBAL__N_120vnet16_fusedn_kernelILb0ELi2EEEvPKflS2_S2_S2_S2_S2_S2_PflS3_S3_liS2_liPKhPyl";
 
 struct Args {
     const float* y; long y_ld; const float *W1, *b1, *W2, *b2, *W3, *b3; float* dec; long dec_ld; float* logits; float* fm;
-    long B; int T; const float* tx; long tx_ld; int K; const unsigned char* mask; unsigned long long* counters;
+    long B; int T; const float* tx; long tx_ld; int K; const unsigned char* mask; unsigned long long* counters; long final_blocks;
 };
 
 static double run(const char* path, Args a, int reps, std::vector<float>* out) {
@@ -23,7 +23,7 @@ static double run(const char* path, Args a, int reps, std::vector<float>* out) {
     CHECK(hipModuleLoad(&mod, path));
     CHECK(hipModuleGetFunction(&fn, mod, kSym));
     void* params[] = {&a.y, &a.y_ld, &a.W1, &a.b1, &a.W2, &a.b2, &a.W3, &a.b3, &a.dec, &a.dec_ld, &a.logits, &a.fm,
-                      &a.B, &a.T, &a.tx, &a.tx_ld, &a.K, &a.mask, &a.counters};
+                      &a.B, &a.T, &a.tx, &a.tx_ld, &a.K, &a.mask, &a.counters, &a.final_blocks};
     const unsigned grid = (unsigned)((a.B + 3) / 4);
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     std::vector<double> ts;
@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
     for (auto& v : W3) v = 0.14f * ud(rng); for (auto& v : b3) v = 0.14f * ud(rng);
     auto up = [](const std::vector<float>& h) { float* d; CHECK(hipMalloc(&d, h.size() * 4)); CHECK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice)); return d; };
     Args a{}; a.y = up(y); a.y_ld = T; a.W1 = up(W1); a.b1 = up(b1); a.W2 = up(W2); a.b2 = up(b2); a.W3 = up(W3); a.b3 = up(b3);
-    CHECK(hipMalloc(&a.dec, (size_t)B * T * 4)); CHECK(hipMemset(a.dec, 0, (size_t)B * T * 4)); a.dec_ld = T; a.B = B; a.T = T;
+    CHECK(hipMalloc(&a.dec, (size_t)B * T * 4)); CHECK(hipMemset(a.dec, 0, (size_t)B * T * 4)); a.dec_ld = T; a.B = B; a.T = T; a.final_blocks = 5120;
     std::vector<float> d0, d1;
     const double ms = run(argv[1], a, 9, &d0);
     printf("%-40s B=%ld  median %.4f ms  = %.1f cycles/symbol/SIMD @2.4GHz", argv[1], B, ms, ms * 1e-3 * 2.4e9 * 1024 / ((double)B * T));
