@@ -40,19 +40,31 @@ def golden_weights(device):
     return [torch.tensor(g[f"w{i}"], device=device) for i in range(6)]
 
 
-def measured_traffic(kernel, B, prefix=False):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, collected with
-    tools/pmc_traffic.sh on this same command); None when the workload differs from the profiled one."""
+def csrc_sha16():
+    """sha256 over the kernel sources: profiles/*.json measurements record the build they were taken on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "meta-viterbinet_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profiled(path, kernel, field, workload):
+    """A per-launch counter value (HBM bytes, VALU instructions) from a committed rocprofv3 PMC summary
+    (profiles/traffic.json, profiles/valu_insts.json; collected with tools/pmc_traffic.sh on this same command).
+    Returns (value, source): value is None when the file is for another workload or kernel, or was taken on another
+    build of the kernels (the file records the sha of csrc/ it was measured on) -- a stale number is not reported."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        w = t["workload"]
-        if (w["blocks"], w["block_length"], w["n_states"]) == (B, T, S):
-            if prefix:  # template arguments vary (e.g. <0, true>): match on the kernel's base name
-                kernel = next(k for k in t if k.startswith(kernel + "<"))
-            return t[kernel]["bytes_per_launch"]
-    except (OSError, KeyError, ValueError, StopIteration):
-        pass
-    return None
+        t = json.load(open(os.path.join(ROOT, "profiles", path)))
+        if workload is not None and [t["workload"][k] for k in ("blocks", "block_length", "n_states")] != list(workload):
+            return None, f"profiles/{path}: profiled workload differs"
+        if t.get("csrc_sha16") != csrc_sha16():
+            return None, f"profiles/{path}: taken on another build of csrc/ ({t.get('csrc_sha16')}), not reported"
+        return t[kernel][field], f"profiles/{path} (offline rocprofv3 --pmc passes on this command, csrc {t['csrc_sha16']})"
+    except (OSError, KeyError, ValueError):
+        return None, f"profiles/{path}: no entry for {kernel}"
 
 
 def event_time_ms(fn, iters, stream_device):
@@ -60,7 +72,7 @@ def event_time_ms(fn, iters, stream_device):
     (the ABI is called with torch's current stream, so torch.cuda.Event brackets exactly those launches)."""
     start = torch.cuda.Event(enable_timing=True)
     stop = torch.cuda.Event(enable_timing=True)
-    for _ in range(3):  # warm: first launches of a variant pay cache / clock ramp effects
+    for _ in range(5):  # warm: first launches of a variant pay cache / clock ramp effects
         fn()
     torch.cuda.synchronize(stream_device)
     start.record()
@@ -106,6 +118,175 @@ def cpu_baseline_torch_path(weights_np, seed):
     return {"value": blocks * T / dt, "unit": "symbols/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle/torch_path.vnet_val (op-for-op PyTorch-CPU restatement of the reference's forward('val')) on "
                       f"{blocks} blocks x {T} symbols, {dt:.1f} s"}
+
+
+VALU_PEAK_GIPS = 1024 * 2.4 / 2.0  # wave-instructions/ns: 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU op (MI355X_MICROARCH.md)
+
+
+def kernel_name(fn, *a):
+    buf = ctypes.create_string_buffer(96)
+    assert fn(*a, buf, 96) == 0
+    return buf.value.decode()
+
+
+def valu_roofline(kernel, B, T_, S_, ms):
+    """VALU-issue roofline of a VALU-bound kernel: wave-instructions per launch (SQ_INSTS_VALU, committed PMC pass) /
+    launch time, against 1024 SIMDs x one wave64 instruction per 2 cycles."""
+    insts, src = profiled("valu_insts.json", kernel, "valu_insts_per_launch", None)
+    if insts is not None:
+        w = json.load(open(os.path.join(ROOT, "profiles", "valu_insts.json")))[kernel]
+        if [w["blocks"], w["block_length"], w["n_states"]] != [B, T_, S_]:
+            insts, src = None, "profiles/valu_insts.json: profiled workload differs"
+    ach = None if insts is None else insts / (ms * 1e-3) / 1e9
+    return {"kernel": kernel, "bound": "valu", "achieved": ach, "peak": VALU_PEAK_GIPS * 1e9 / 1e9, "unit": "G wave-instr/s",
+            "frac": None if ach is None else ach / VALU_PEAK_GIPS, "valu_insts_per_launch": insts, "insts_source": src,
+            "state_steps_per_s": B * T_ * S_ / (ms * 1e-3), "algorithmic_hbm_bytes": 8.0 * B * T_, "ms_per_launch": ms}
+
+
+def wall_ms(fn, dev, reps=1):
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / reps * 1e3, r
+
+
+def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
+    """The other BASELINE.json configs, outside the headline timed region; every rank takes part (collectives), rank 0
+    reports.  [0] VA L=4 100 x 1000 (one GPU's worth; rank 0), [2] ViterbiNet over the COST2100 taps, 300 blocks by word
+    (block-sharded when no update runs between blocks, replicas otherwise), [3] VA L=8 at the per-GPU share of 10^6
+    blocks, [4] the Meta-ViterbiNet online flow with the reference's default counts (replicas)."""
+    lib = mvn._lib.load()
+    st = mvn._lib.current_stream(dev)
+    out = []
+    coef = {"train": "time_decay", "val": "time_decay"}
+
+    def max_over_ranks(ms):
+        if world == 1:
+            return ms
+        t = torch.tensor([ms], dtype=torch.float64, device=dev)
+        all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- configs[0]: classical VA, L=4, 100 blocks x 1000 symbols (the reference's CPU-runnable case)
+    B0, T0 = 100, 1000
+    tx0, y0 = mvn.synthetic_words(B0, T0, 4, SNR_DB, GAMMA, dev, seed=3450002)
+    va = mvn.VADetector(16, 4, T0, 1, "ISI_AWGN", 0, False, 1, coef)
+    pri = va.compute_state_priors(mvn.estimate_channel(4, GAMMA, "time_decay")).to(dev).T.contiguous()
+    dec0 = torch.zeros_like(y0)
+    ms0 = event_time_ms(lambda: lib.mvn_va_decode_f32(mvn._lib.ptr(y0), T0, mvn._lib.ptr(pri), 1, mvn._lib.ptr(dec0), T0, None,
+                                                      B0, T0, 16, st), 20, dev)
+    ms0_fwd = event_time_ms(lambda: va(y0, "val", SNR_DB, GAMMA), 10, dev)
+    ser0, fer0 = mvn.rates_from_counters(mvn.count_errors(va(y0, "val", SNR_DB, GAMMA), tx0))
+    k0 = kernel_name(lib.mvn_va_decode_kernel_name, B0, T0, 16)
+    out.append({"config": "BASELINE configs[0]: classical VA, L=4 (16 states), 100 blocks x 1000 symbols", "n_gpus": 1,
+                "ms": ms0, "symbols_per_s": B0 * T0 / (ms0 * 1e-3), "ms_detector_forward": ms0_fwd, "ser": ser0, "fer": fer0,
+                "kernel": k0, "roofline": valu_roofline(k0, B0, T0, 16, ms0),
+                "note": "25-100 waves on a 4096-slot chip: latency-bound by construction at this batch size"})
+
+    # ---- configs[3]: VA L=8 (256 states), 10^6 blocks over 8 GPUs = 125 000 blocks x 1000 symbols per GPU (weak scaling)
+    B3, T3, L3 = 125000, 1000, 8
+    tx3, y3 = mvn.synthetic_words(B3, T3, L3, SNR_DB, GAMMA, dev, seed=3450002 + 17 * rank)
+    va8 = mvn.VADetector(256, L3, T3, 1, "ISI_AWGN", 0, False, 1, coef)
+    pri8 = va8.compute_state_priors(mvn.estimate_channel(L3, GAMMA, "time_decay")).to(dev).T.contiguous()
+    dec3 = torch.empty_like(y3)
+    ms3 = max_over_ranks(event_time_ms(lambda: lib.mvn_va_decode_f32(mvn._lib.ptr(y3), T3, mvn._lib.ptr(pri8), 1, mvn._lib.ptr(dec3),
+                                                                     T3, None, B3, T3, 256, st), 5, dev))
+    c3 = mvn.count_errors(dec3, tx3)
+    if world > 1:
+        all_reduce(c3)
+    ser3, fer3 = mvn.rates_from_counters(c3)
+    k3 = kernel_name(lib.mvn_va_decode_kernel_name, B3, T3, 256)
+    out.append({"config": "BASELINE configs[3]: VA L=8 (256 states), 10^6 blocks x 1000 symbols over 8 GPUs = 125 000 blocks per GPU",
+                "n_gpus": world, "blocks_per_gpu": B3, "ms": ms3, "symbols_per_s": world * B3 * T3 / (ms3 * 1e-3),
+                "ser": ser3, "fer": fer3, "frames": int(c3[3].item()), "kernel": k3, "roofline": valu_roofline(k3, B3, T3, 256, ms3),
+                "parallelism": f"block-sharded x{world}, one all-reduce of int64[4] counters"})
+    del tx3, y3, dec3
+
+    if not by_word:  # (profiling runs: the two VA configs only)
+        return out
+    # ---- configs[2] / [4]: 300 blocks by word (T = 120 + 8*2, RS(17,15)), ViterbiNet weights trained on the reference
+    N, K, nsym, L, sub = 300, 120, 2, 4, 25
+    g7 = np.load(os.path.join(ROOT, "tests", "golden", "g7_by_word.npz"))
+
+    def make_det():
+        det = mvn.VNETDetector(16, {"train": K + 8 * nsym, "val": K + 8 * nsym}).to(dev)
+        with torch.no_grad():
+            for p_, i in zip(det.parameters(), range(6)):
+                p_.copy_(torch.tensor(g7[f"w{i}"]))
+        return det
+
+    def words(coefficients, snr, seed):
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        msg = torch.randint(0, 2, (N, K), generator=gen, device=dev).float()
+        cw = mvn.rs_encode(msg, nsym)
+        if coefficients == "cost2100":
+            h = np.concatenate([mvn.estimate_channel(L, GAMMA, "cost2100", index=i) for i in range(N)])
+        else:
+            h = np.concatenate([mvn.estimate_channel(L, GAMMA, "time_decay", fading=True, index=i, fading_taps_type=2)
+                                for i in range(N)])
+        return msg, mvn.transmit(cw, h, snr, L, torch.randn(N, K + 8 * nsym, generator=gen, device=dev))
+
+    rows = mvn.data_indices(N // sub, sub).to(dev)
+    msg, rx = words("cost2100", SNR_DB, 5)
+    det = make_det()
+    # (a) no update between blocks: blocks are independent -> ONE batched, block-sharded call (decode, RS decode, count)
+    mvn.sharded_eval(det, msg, rx, SNR_DB, GAMMA, rows, n_symbols=nsym, rank=rank, world=world)
+    ms2a, (ser2a, fer2a, c2a) = wall_ms(lambda: mvn.sharded_eval(det, msg, rx, SNR_DB, GAMMA, rows, n_symbols=nsym, rank=rank,
+                                                                 world=world), dev, reps=5)
+    # (b) the reference's call pattern: 300 sequential B=1 calls, no update (rank 0)
+    mvn.eval_by_word(det, msg[:5], rx[:5], SNR_DB, GAMMA, nsym, sub)
+    ms2b, ser_seq = wall_ms(lambda: mvn.eval_by_word(det, msg, rx, SNR_DB, GAMMA, nsym, sub), dev)
+    kfused = kernel_name(lib.mvn_vnet_decode_kernel_name, 1, K + 8 * nsym, 16, 0)
+
+    # (c) self-supervised online training after every block: does not shard within a trial -> replicas (SNR x seed grid)
+    def trial_selfsup(i):
+        m_, r_ = words("cost2100", 7.0 + (i % 6), 100 + i)  # plotter_main.py:117-122: 7..12 dB
+        d_ = make_det()
+        return mvn.eval_by_word(d_, m_, r_, 7.0 + (i % 6), GAMMA, nsym, sub, self_supervised=True,
+                                online_trainer=mvn.OnlineTrainer(d_, L), self_supervised_iterations=200)
+
+    trial_selfsup(0)  # warm
+    ms2c, rep2 = wall_ms(lambda: mvn.replica_eval(trial_selfsup, world, rank=rank, world=world,
+                                                  device=dev if backend == "nccl" else "cpu"), dev)
+    ms2c = max_over_ranks(ms2c)
+    T2 = K + 8 * nsym
+    out.append({"config": "BASELINE configs[2]: ViterbiNet L=4, COST2100 taps, 300-block evaluation by word (T=136, RS(17,15))",
+                "n_gpus": world, "kernel": kfused,
+                "joint_batched_block_sharded": {"ms": ms2a, "symbols_per_s": N * T2 / (ms2a * 1e-3), "coded_ser": ser2a,
+                                                "what": "no update between blocks => independent: one decode + one RS + one count launch "
+                                                        f"for all 300 blocks, rows sharded x{world}, one all-reduce of int64[4]"},
+                "joint_sequential_b1": {"ms": ms2b, "us_per_block": ms2b * 1e3 / N, "symbols_per_s": N * T2 / (ms2b * 1e-3),
+                                        "mean_ser": float(np.mean(ser_seq)),
+                                        "what": "the reference's call pattern: 300 x {detect B=1, RS decode, ser, re-encode}"},
+                "self_supervised_replicas": {"ms": ms2c, "us_per_block": ms2c * 1e3 / N, "blocks_per_s": world * N / (ms2c * 1e-3),
+                                             "symbols_per_s": world * N * T2 / (ms2c * 1e-3), "mean_ser_by_trial": [float(v) for v in np.nanmean(rep2, axis=1)],
+                                             "what": f"200 CE+Adam iterations on the HIP training kernel after every block; {world} independent "
+                                                     "trial(s) (SNR 7..12 dB grid), one all_gather of ser_by_word[300]"},
+                "roofline": None,
+                "note": "one wave of work per launch: bound by launch + host-sync latency, not by a device roofline"})
+
+    # ---- configs[4]: Meta-ViterbiNet online retrain + decode, reference defaults (200 / 20 / 10 / 5), replicas
+    def trial_meta(i):
+        m_, r_ = words("time_decay", 7.0 + (i % 6), 200 + i)
+        d_ = make_det()
+        torch.manual_seed(i)
+        return mvn.eval_by_word(d_, m_, r_, 7.0 + (i % 6), GAMMA, nsym, sub, self_supervised=True, online_trainer=mvn.OnlineTrainer(d_, L),
+                                self_supervised_iterations=200, online_meta=True, meta_detector=mvn.META_VNETDetector(16, {"train": T2, "val": T2}),
+                                meta_train_iterations=20, meta_j_num=10, meta_subframes=5, meta_style_online_training=True)
+
+    ms4, rep4 = wall_ms(lambda: mvn.replica_eval(trial_meta, world, rank=rank, world=world, device=dev if backend == "nccl" else "cpu"), dev)
+    ms4 = max_over_ranks(ms4)
+    out.append({"config": "BASELINE configs[4]: Meta-ViterbiNet online retrain + decode, L=4, pilot-aided, 300 blocks (reference defaults: "
+                          "200 full-word iterations per block, every 5 blocks 20 x <=10 MAML steps)",
+                "n_gpus": world, "ms": ms4, "ms_per_block": ms4 / N, "blocks_per_s": world * N / (ms4 * 1e-3),
+                "symbols_per_s": world * N * T2 / (ms4 * 1e-3), "mean_ser_by_trial": [float(v) for v in np.nanmean(rep4, axis=1)],
+                "kernel": "maml_train_kernel + online_train_kernel + " + kfused,
+                "what": f"{world} independent trial(s) (replicas: block k's weights depend on the blocks before it), one all_gather of ser_by_word[300]",
+                "roofline": None, "note": "two single-workgroup training kernels per block: bound by one CU's LDS / issue rate, see DESIGN.md 5.5"})
+    return out
+
 
 
 def _free_port():
@@ -159,7 +340,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=10000, help="blocks per GPU (BASELINE configs[1]: 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config entries (BASELINE configs[0],[2],[3],[4])")
-    ap.add_argument("--skip-fused-count", action="store_true", help="(profiling) keep every fused-kernel dispatch decode-only: no fused-count timing, no FER curve")
+    ap.add_argument("--skip-fused-count", action="store_true", help="(profiling) keep every fused-kernel dispatch decode-only: no fused-count timing, no FER curve, no by-word configs")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -264,12 +445,12 @@ def main():
         ms_step = event_time_ms(step, 3, dev)
         cfused = torch.zeros(4, dtype=torch.int64, device=dev)
         ms_fused_count = float("nan") if args.skip_fused_count else event_time_ms(lambda: det.val_count(y, tx, None, cfused), 10, dev)
-        del cost
         mlp_tflops = FLOP_PER_SYMBOL * B * T / (ms_fused * 1e-3) / 1e12
         acs_gbps = ACS_BYTES_PER_SYMBOL * B * T / (ms_acs * 1e-3) / 1e9
-        name_buf = ctypes.create_string_buffer(64)
-        assert lib.mvn_acs_sweep_kernel_name(B, T, S, name_buf, 64) == 0
-        acs_kernel = name_buf.value.decode()
+        acs_kernel = kernel_name(lib.mvn_acs_sweep_kernel_name, mvn._lib.ptr(cost), mvn._lib.ptr(dec), T, B, T, S)
+        fused_kernel = kernel_name(lib.mvn_vnet_decode_kernel_name, B, T, S, 0)
+        traffic_fused, traffic_fused_src = profiled("traffic.json", fused_kernel, "bytes_per_launch", (B, T, S))
+        traffic_acs, traffic_acs_src = profiled("traffic.json", acs_kernel, "bytes_per_launch", (B, T, S))
         out = {
             "metric": "decoded symbols/sec, ViterbiNet L=4 ISI (16 states)",
             "value": total_symbols / elapsed,
@@ -290,17 +471,16 @@ def main():
             "ser_at_snr": ser,
             "fer_at_snr": fer,
             "fer_curve": fer_curve,
-            "roofline": {"kernel": "vnet16_fused4_kernel<false> (ViterbiNet MLP on f32 MFMA 16x16x4 + 4x4x1, in-place DPP trellis sweep)", "bound": "mfma",
+            "roofline": {"kernel": fused_kernel + " (ViterbiNet MLP on f32 MFMA 16x16x4, in-place DPP trellis sweep)", "bound": "mfma",
                          "achieved": mlp_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": mlp_tflops / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": measured_traffic("vnet16_fused4_kernel<false>", B), "traffic_unit": "HBM bytes/launch",
+                         "traffic": traffic_fused, "traffic_unit": "HBM bytes/launch", "traffic_source": traffic_fused_src,
                          "algorithmic_hbm_bytes": 8.0 * B * T,
                          "ms_per_launch": ms_fused, "flop_per_symbol": FLOP_PER_SYMBOL},
-            "roofline_acs_sweep": {"kernel": acs_kernel + "<COST> (mvn_acs_sweep_f32, LDS-DMA streamed costs)", "bound": "hbm",
+            "roofline_acs_sweep": {"kernel": acs_kernel + " (mvn_acs_sweep_f32, LDS-DMA streamed costs)", "bound": "hbm",
                                    "achieved": acs_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                    "frac": acs_gbps / PEAK_HBM_GBPS,
-                                   "traffic": measured_traffic(acs_kernel, B, prefix=True),
-                                   "traffic_unit": "HBM bytes/launch", "algorithmic_hbm_bytes": ACS_BYTES_PER_SYMBOL * B * T,
+                                   "traffic": traffic_acs, "traffic_unit": "HBM bytes/launch", "traffic_source": traffic_acs_src, "algorithmic_hbm_bytes": ACS_BYTES_PER_SYMBOL * B * T,
                                    "ms_per_launch": ms_acs,
                                    "bytes_per_symbol": ACS_BYTES_PER_SYMBOL},
             "ms_per_step_events": ms_step,
@@ -308,6 +488,11 @@ def main():
                                            "store (4 B/symbol of HBM traffic); same counters as `value`'s two-launch step",
                                    "ms_per_step": ms_fused_count, "symbols_per_s": B * T / (ms_fused_count * 1e-3)},
         }
+    # the other BASELINE configs: after the headline kernels were timed (the by-word configs are latency-bound and let the
+    # clocks drop), every rank takes part
+    configs = [] if args.no_configs else run_configs(dev, rank, world, all_reduce, backend, weights, by_word=not args.skip_fused_count)
+    if rank == 0:
+        out["configs"] = configs
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline([w.cpu().numpy() for w in weights], 3450002)
             out["cpu_baseline_torch_path"] = cpu_baseline_torch_path([w.cpu().numpy() for w in weights], 3450002)

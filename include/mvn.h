@@ -19,9 +19,12 @@
  *     (va_detector.py:90-93); columns >= T of `dec` are not touched (caller zero-fills).
  *   - arithmetic is IEEE fp32 with one rounding per reference operation; results are
  *     bit-identical to oracle/mvn_oracle.c for finite inputs, for +-inf, and for NaN samples in y
- *     (all branch costs of that symbol become NaN, as in the reference); a NaN in only SOME of a
- *     symbol's branch costs (e.g. NaN weights or priors) is unspecified: torch.min propagates it,
- *     v_min_f32 does not.
+ *     (all branch costs of that symbol become NaN, as in the reference).  mvn_acs_block_f32 propagates NaN like
+ *     torch.min.  DEVIATION, pinned by tests/test_gpu_parity.py::test_partial_nan_costs_are_dropped_by_the_sweeps: inside
+ *     the sweeps a NaN in only ONE of a state's two candidates (possible through NaN in some of a symbol's branch
+ *     costs, priors or last-layer weights only) is dropped -- the stage is v_min_f32 = fminf -- where torch.min would
+ *     return NaN; a state both of whose candidates are NaN becomes NaN, and the decision rule (first NaN, else first
+ *     minimum) is torch.argmin's.
  */
 #ifndef MVN_H_
 #define MVN_H_
@@ -43,7 +46,7 @@ typedef void *mvn_stream_t; /* hipStream_t */
 #define MVN_E_WORKSPACE (-5) /* workspace too small for one block */
 #define MVN_E_DEVICE (-6)    /* current device is not gfx950 */
 
-#define MVN_ABI_VERSION 1
+#define MVN_ABI_VERSION 2 /* 2: kernel-name queries take the buffers; mvn_va/vnet_decode_kernel_name */
 
 /* ABI version of the loaded library (== MVN_ABI_VERSION). */
 int mvn_version(void);
@@ -74,10 +77,16 @@ int mvn_acs_sweep_f32(const float *cost, float *dec, int64_t dec_ld, float *fina
 
 /*
  * Introspection for profiling tools (no reference counterpart): name of the device kernel mvn_acs_sweep_f32
- * launches for this shape on the current device, honouring the MVN_* environment switches.  Host pointer;
- * returns 0, or MVN_E_STATES / MVN_E_NULL.
+ * launches for these buffers and this shape on the current device: the dispatcher's own decision (same MVN_*
+ * environment switches, same fall-backs for buffers that are not 16-byte aligned; `cost` / `dec` are only inspected
+ * for their alignment and may be NULL = aligned).  `name` is a host pointer; returns 0, or MVN_E_STATES / MVN_E_NULL.
  */
-int mvn_acs_sweep_kernel_name(int64_t B, int32_t T, int32_t S, char *name, int32_t name_len);
+int mvn_acs_sweep_kernel_name(const float *cost, const float *dec, int64_t dec_ld, int64_t B, int32_t T, int32_t S,
+                              char *name, int32_t name_len);
+/* The same for mvn_va_decode_f32 and mvn_vnet_decode_f32 (two launches are reported as "a + b"; the scratch sweep of
+ * the two-launch ViterbiNet route is named for 16-byte aligned buffers). */
+int mvn_va_decode_kernel_name(int64_t B, int32_t T, int32_t S, char *name, int32_t name_len);
+int mvn_vnet_decode_kernel_name(int64_t B, int32_t T, int32_t S, int32_t want_logits, char *name, int32_t name_len);
 
 /*
  * VADetector.forward(y,'val'), python_code/detectors/VA/va_detector.py:73-98, given the

@@ -4,7 +4,7 @@ from . import _lib
 from .channel import BPSKModulator, estimate_channel, transmit
 from .detectors import HIDDEN1_SIZE, HIDDEN2_SIZE, META_VNETDetector, VADetector, VNETDetector
 from .ecc import rs_decode, rs_encode
-from .harness import (data_indices, detect_by_word, eval_by_word, eval_counters, shard_range, sharded_eval,
+from .harness import (data_indices, detect_by_word, eval_by_word, eval_counters, replica_eval, shard_range, sharded_eval,
                       single_eval_at_point, synthetic_words)
 from .meta import GraphedMetaStep, copy_model, meta_train_loop
 from .online import OnlineTrainer
@@ -17,5 +17,5 @@ __all__ = [
     "calculate_error_rates", "count_errors", "rates_from_counters",
     "estimate_channel", "BPSKModulator", "transmit", "rs_encode", "rs_decode", "OnlineTrainer", "meta_train_loop", "GraphedMetaStep", "copy_model",
     "shard_range", "data_indices", "synthetic_words", "eval_counters", "single_eval_at_point",
-    "sharded_eval", "detect_by_word", "eval_by_word",
+    "sharded_eval", "detect_by_word", "eval_by_word", "replica_eval",
 ]

@@ -9,7 +9,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVN_LIB_PATH", os.path.join(_PKG, "libmvn_hip.so"))  # override: A/B builds
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -23,7 +23,9 @@ SIGNATURES = {
                                        ctypes.c_char_p, ctypes.c_int]),
     "mvn_acs_block_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "mvn_acs_sweep_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
-    "mvn_acs_sweep_kernel_name": (ctypes.c_int, [_i64, _i32, _i32, ctypes.c_char_p, _i32]),
+    "mvn_acs_sweep_kernel_name": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i32, _i32, ctypes.c_char_p, _i32]),
+    "mvn_va_decode_kernel_name": (ctypes.c_int, [_i64, _i32, _i32, ctypes.c_char_p, _i32]),
+    "mvn_vnet_decode_kernel_name": (ctypes.c_int, [_i64, _i32, _i32, _i32, ctypes.c_char_p, _i32]),
     "mvn_va_decode_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
     "mvn_vnet_logits_f32": (ctypes.c_int, [_vp] * 8 + [_i64, _i32, _vp]),
     "mvn_vnet_workspace_bytes": (ctypes.c_size_t, [_i64, _i32, _i32]),

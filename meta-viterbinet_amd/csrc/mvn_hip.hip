@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void acs_block_kernel(const float *__restrict_
     const int p0 = (2 * s) % S, p1 = (2 * s + 1) % S;
     const float v0 = in_prob[b * S + p0] + llrs[b * S + p0];
     const float v1 = in_prob[b * S + p1] + llrs[b * S + p1];
-    const bool second = v1 < v0;  // first minimal index wins
+    const bool second = !(v1 >= v0) && v0 == v0;  // torch.min(dim): first minimal index wins, NaN propagates (first NaN wins)
     out[e] = second ? v1 : v0;
     if (argmin_j) argmin_j[e] = second ? 1 : 0;
 }
@@ -546,51 +546,90 @@ int launch_vnet16_fused(const float *y, int64_t y_ld, const float *W1, const flo
     return (int)hipGetLastError();
 }
 
-// MVN_GENERIC_SWEEP=1 forces the generic state-per-lane LDS sweep at S=16 (testing).
-bool generic_sweep_forced() {
-    const char *e = getenv("MVN_GENERIC_SWEEP");
-    return e && e[0] == '1';
+// The MVN_* switches (A/B runs, cross-checks in the tests).  Read through getenv on every call so that a test can flip them
+// between two calls; a getenv of an unset name is a ~20 ns scan of the environment block.
+bool env_is(const char *name, char c) {
+    const char *e = getenv(name);
+    return e && e[0] == c;
+}
+// MVN_GENERIC_SWEEP=1 forces the generic state-per-lane LDS sweep for every S (testing).
+bool generic_sweep_forced() { return env_is("MVN_GENERIC_SWEEP", '1'); }
+
+// Which kernel serves a sweep: ONE decision function used by the dispatcher and by the mvn_*_kernel_name queries, so the
+// name a caller is told is the kernel that runs (same environment switches, same alignment fall-backs).
+enum SweepKind { SK_GENERIC, SK_VA_INPLACE, SK_SWEEP_INPLACE, SK_S16_QUAD, SK_S16_LDS, SK_S16_ROWS, SK_VA16_QUAD };
+
+template <int MODE>
+SweepKind plan_sweep(const void *src, const void *dec, int64_t dec_ld, int64_t B, int S) {
+    const bool generic = generic_sweep_forced();
+    if constexpr (MODE == MODE_VA) {
+        // classical VA: the lane-bits x register-bits in-place kernel serves every S >= 4 except S = 16, which has its
+        // own 16-blocks-per-wave / row kernels (MVN_VA_INPLACE=1 sends S = 16 there too, for cross-checks)
+        if (S >= 4 && !generic && (S != 16 || env_is("MVN_VA_INPLACE", '1'))) return SK_VA_INPLACE;
+        if (S == 16 && !generic) {  // MVN_VA16 = "rows" | "quad" pins a variant (A/B, tests); default by size
+            const char *e = getenv("MVN_VA16");
+            return (e ? e[0] == 'q' : B >= kVaQuadMinBlocks) ? SK_VA16_QUAD : SK_S16_ROWS;
+        }
+        return SK_GENERIC;
+    } else {
+        // materialised costs: the LDS-DMA kernels move 16-byte pieces and store float4 decisions; buffers that are not
+        // 16-byte aligned take the row kernel (S = 16) or the generic kernel
+        const bool aligned = !((reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dec) & 15) || (dec_ld & 3));
+        if (S >= 4 && !generic && aligned && (S != 16 || env_is("MVN_SWEEP_INPLACE", '1'))) return SK_SWEEP_INPLACE;
+        if (S == 16 && !generic) {
+            if (reinterpret_cast<uintptr_t>(src) & 15) return SK_S16_ROWS;
+            const char *e = getenv("MVN_SWEEP16");  // "rows" | "lds" | "quad" pins a variant; default by size
+            const char v = (e && (e[0] == 'q' || e[0] == 'l' || e[0] == 'r')) ? e[0] : (sweep16_quad_preferred(B) ? 'q' : 'l');
+            return v == 'q' ? SK_S16_QUAD : v == 'l' ? SK_S16_LDS : SK_S16_ROWS;
+        }
+        return SK_GENERIC;
+    }
 }
 
-// which cost-streaming kernel serves a 16-state sweep: 'q'uad, 'l'ds or 'r'ows
-char sweep16_variant(int64_t B) {
-    const char *e = getenv("MVN_SWEEP16");  // "rows" | "lds" | "quad" pins a variant (A/B, tests); default by size
-    if (e && (e[0] == 'q' || e[0] == 'l' || e[0] == 'r')) return e[0];
-    return sweep16_quad_preferred(B) ? 'q' : 'l';
+int log2_states(int S) {
+    int l = 0;
+    while ((1 << l) < S) ++l;
+    return l;
+}
+
+template <int MODE>
+void sweep_kernel_name(SweepKind k, int S, const void *dec, int64_t dec_ld, char *name, size_t n) {
+    const int lb = log2_states(S) - 2;
+    switch (k) {
+        case SK_VA_INPLACE: snprintf(name, n, "va_inplace_kernel<%d>", lb); break;
+        case SK_SWEEP_INPLACE: snprintf(name, n, "sweep_inplace_kernel<%d, %d, %d>", lb, MODE, lb >= 2 ? 4 : lb == 1 ? 8 : 16); break;
+        case SK_S16_QUAD:
+            snprintf(name, n, "sweep16_quad_kernel<%d, %s>", MODE,
+                     ((dec_ld % 4) == 0 && (reinterpret_cast<uintptr_t>(dec) % 16) == 0) ? "true" : "false");
+            break;
+        case SK_S16_LDS: snprintf(name, n, "sweep16_lds_kernel<%d>", MODE); break;
+        case SK_S16_ROWS: snprintf(name, n, "sweep16_rows_kernel<%d>", MODE); break;
+        case SK_VA16_QUAD: snprintf(name, n, "va16_quad_kernel"); break;
+        default: snprintf(name, n, "sweep_kernel<%d, %d>", S, MODE); break;
+    }
 }
 
 template <int MODE>
 int dispatch_sweep(const float *src, int64_t src_ld, const float *priors, int64_t Bp, float *dec, int64_t dec_ld,
                    float *final_metric, int64_t B, int T, int S, hipStream_t st) {
-    if constexpr (MODE == MODE_VA) {
-        // classical VA: the lane-bits x register-bits in-place kernel serves every S >= 4 except S = 16, which has its
-        // own 16-blocks-per-wave / row kernels below (MVN_VA_INPLACE=1 sends S = 16 here too, for cross-checks)
-        const char *e = getenv("MVN_VA_INPLACE");
-        if (S >= 4 && !generic_sweep_forced() && (S != 16 || (e && e[0] == '1')))
-            return launch_va_inplace(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, S, st);
-    }
-    if constexpr (MODE != MODE_VA) {
-        // materialised costs at S != 16: in-place recurrence + LDS-DMA streaming for any S >= 4 (MVN_SWEEP_INPLACE=1 sends
-        // S = 16 here too, for cross-checks); unaligned buffers and S = 2 fall through to the generic kernel
-        const char *e = getenv("MVN_SWEEP_INPLACE");
-        if (S >= 4 && !generic_sweep_forced() && (S != 16 || (e && e[0] == '1'))) {
-            const int rc = launch_sweep_inplace<MODE>(src, dec, dec_ld, final_metric, B, T, S, st);
-            if (rc != -1) return rc;
-        }
-    }
-    if (S == 16 && !generic_sweep_forced()) {
-        if constexpr (MODE != MODE_VA) {  // materialised costs: stream them through LDS in 1-KB pieces
-            // the LDS-DMA kernels move 16-byte pieces: a cost tensor that is not 16-byte aligned takes the row kernel
-            const char v = (reinterpret_cast<uintptr_t>(src) & 15) ? 'r' : sweep16_variant(B);
-            if (v == 'q') return launch_sweep16_quad<MODE>(src, dec, dec_ld, final_metric, B, T, st);
-            if (v != 'r') return launch_sweep16_lds<MODE>(src, dec, dec_ld, final_metric, B, T, st);
-        }
-        if constexpr (MODE == MODE_VA) {  // MVN_VA16 = "rows" | "quad" pins a variant (A/B, tests); default by size
-            const char *e = getenv("MVN_VA16");
-            if (e ? e[0] == 'q' : B >= kVaQuadMinBlocks)
-                return launch_va16_quad(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
-        }
-        return launch_sweep16_rows<MODE>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
+    switch (plan_sweep<MODE>(src, dec, dec_ld, B, S)) {
+        case SK_VA_INPLACE:
+            if constexpr (MODE == MODE_VA) return launch_va_inplace(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, S, st);
+            break;
+        case SK_VA16_QUAD:
+            if constexpr (MODE == MODE_VA) return launch_va16_quad(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
+            break;
+        case SK_SWEEP_INPLACE:
+            if constexpr (MODE != MODE_VA) return launch_sweep_inplace<MODE>(src, dec, dec_ld, final_metric, B, T, S, st);
+            break;
+        case SK_S16_QUAD:
+            if constexpr (MODE != MODE_VA) return launch_sweep16_quad<MODE>(src, dec, dec_ld, final_metric, B, T, st);
+            break;
+        case SK_S16_LDS:
+            if constexpr (MODE != MODE_VA) return launch_sweep16_lds<MODE>(src, dec, dec_ld, final_metric, B, T, st);
+            break;
+        case SK_S16_ROWS: return launch_sweep16_rows<MODE>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
+        default: break;
     }
     return launch_sweep<MODE>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, S, st);
 }
@@ -662,16 +701,34 @@ int mvn_acs_sweep_f32(const float *cost, float *dec, int64_t dec_ld, float *fina
                                    (hipStream_t)stream);
 }
 
-int mvn_acs_sweep_kernel_name(int64_t B, int32_t T, int32_t S, char *name, int32_t name_len) {
+int mvn_acs_sweep_kernel_name(const float *cost, const float *dec, int64_t dec_ld, int64_t B, int32_t T, int32_t S,
+                              char *name, int32_t name_len) {
     (void)T;
     if (!valid_states(S)) return MVN_E_STATES;
     if (!name || name_len < 1) return MVN_E_NULL;
-    const char *k = "sweep_kernel";
-    if (S == 16 && !generic_sweep_forced()) {
-        const char v = sweep16_variant(B);
-        k = v == 'q' ? "sweep16_quad_kernel" : v == 'l' ? "sweep16_lds_kernel" : "sweep16_rows_kernel";
+    sweep_kernel_name<MODE_COST>(plan_sweep<MODE_COST>(cost, dec, dec_ld, B, S), S, dec, dec_ld, name, (size_t)name_len);
+    return MVN_OK;
+}
+
+int mvn_va_decode_kernel_name(int64_t B, int32_t T, int32_t S, char *name, int32_t name_len) {
+    (void)T;
+    if (!valid_states(S)) return MVN_E_STATES;
+    if (!name || name_len < 1) return MVN_E_NULL;
+    sweep_kernel_name<MODE_VA>(plan_sweep<MODE_VA>(nullptr, nullptr, 0, B, S), S, nullptr, 0, name, (size_t)name_len);
+    return MVN_OK;
+}
+
+int mvn_vnet_decode_kernel_name(int64_t B, int32_t T, int32_t S, int32_t want_logits, char *name, int32_t name_len) {
+    (void)T;
+    if (!valid_states(S)) return MVN_E_STATES;
+    if (!name || name_len < 1) return MVN_E_NULL;
+    if (S == 16 && !unfused_forced()) {
+        snprintf(name, (size_t)name_len, "vnet16_fusedn_kernel<%s, %d>", want_logits ? "true" : "false", fusedn_tiles());
+    } else {  // two launches: the MLP, then the sweep over its logits (scratch or logits_out: 16-byte aligned, row stride T)
+        char sw[64];
+        sweep_kernel_name<MODE_NEGLOGIT>(plan_sweep<MODE_NEGLOGIT>(nullptr, nullptr, 0, B, S), S, nullptr, 0, sw, sizeof sw);
+        snprintf(name, (size_t)name_len, "mlp_kernel<%d> + %s", (S + 15) / 16, sw);
     }
-    snprintf(name, (size_t)name_len, "%s", k);
     return MVN_OK;
 }
 
@@ -760,9 +817,12 @@ int mvn_vnet_online_train_f32(const float *y, const int32_t *labels, int32_t T, 
     if (n_iter == 0) return MVN_OK;
     if (!y || !labels || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !adam_m || !adam_v) return MVN_E_NULL;
     const size_t lds = online_train_lds_bytes(S);
-    hipError_t e = hipFuncSetAttribute((const void *)online_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return (int)e;
+    static size_t lds_allowed = 0;  // the opt-in to > 64 KB of dynamic LDS is per function, not per launch: raise it when needed
+    if (lds > lds_allowed) {
+        hipError_t e = hipFuncSetAttribute((const void *)online_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        lds_allowed = lds;
+    }
     hipLaunchKernelGGL(online_train_kernel, dim3(1), dim3(kTrainThreads), lds, (hipStream_t)stream, y, labels, T, batch_idx,
                        M, n_iter, W1, b1, W2, b2, W3, b3, adam_m, adam_v, pow((double)beta1, (double)step0),
                        pow((double)beta2, (double)step0), lr, beta1, beta2, eps, loss_out, S, (int)online_train_lds_floats(S));
@@ -780,8 +840,12 @@ int mvn_vnet_maml_train_f32(const float *rx_words, const int32_t *labels, int32_
     if (!rx_words || !labels || !support_idx || !query_idx || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !adam_m || !adam_v)
         return MVN_E_NULL;
     const size_t lds = maml_train_lds_floats(S) * sizeof(float);
-    hipError_t e = hipFuncSetAttribute((const void *)maml_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    static size_t lds_allowed = 0;
+    if (lds > lds_allowed) {
+        hipError_t e = hipFuncSetAttribute((const void *)maml_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        lds_allowed = lds;
+    }
     hipLaunchKernelGGL(maml_train_kernel, dim3(1), dim3(kTrainThreads), lds, (hipStream_t)stream, rx_words, labels, T,
                        support_idx, W, query_idx, n_steps, W1, b1, W2, b2, W3, b3, adam_m, adam_v,
                        pow((double)beta1, (double)step0), pow((double)beta2, (double)step0), meta_lr, second_order, lr, beta1,

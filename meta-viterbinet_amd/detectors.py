@@ -60,6 +60,7 @@ class VADetector(nn.Module):
         self.channel_coefficients = channel_coefficients  # dict {'train':..., 'val':...} (trainer.py:195)
         self.transition_table_array = create_transition_table(n_states)
         self.transition_table = torch.Tensor(self.transition_table_array).to(_default_device())
+        self._priors_cache = {}
 
     def _estimate_all(self, gamma: float, phase: str) -> np.ndarray:
         """[val_words, L] float64 taps, one estimate_channel call per word (va_detector.py:54-58)."""
@@ -88,12 +89,23 @@ class VADetector(nn.Module):
         return priors ** 2 / 2 - math.log(math.sqrt(2 * math.pi))
 
     def _priors_table(self, y, gamma, phase, count):
-        h = self._estimate_all(gamma, phase)
-        if count is not None:
-            h = h[count].reshape(1, -1)
+        """[W,S] state priors on y's device ([1,S] for one word when `count` is given).  The reference re-derives the
+        channel of every word on the host at every forward (va_detector.py:54-58); with noisy_est_var == 0 that table is a
+        pure function of (gamma, phase) and the detector's configuration, so it is derived once and kept on the device --
+        a by-word evaluation then costs one row slice per call instead of val_words x estimate_channel + a blocking
+        upload.  noisy_est_var > 0 draws from the global RNG at every call (channel_estimation.py:36): never cached."""
         if self.channel_type != "ISI_AWGN":
             raise Exception("No such channel defined!!!")
-        return self.compute_state_priors(h).to(y.device).T.contiguous()  # [W,S]
+        key = None
+        if not self.noisy_est_var > 0:
+            key = (float(gamma), phase, self.channel_coefficients[phase], self.val_words, self.memory_length, self.n_states,
+                   bool(self.fading), self.fading_taps_type, str(y.device))
+        table = self._priors_cache.get(key) if key is not None else None
+        if table is None:
+            table = self.compute_state_priors(self._estimate_all(gamma, phase)).to(y.device).T.contiguous()  # [W,S]
+            if key is not None:
+                self._priors_cache = {key: table}  # one entry: the configuration an evaluation is running with
+        return table if count is None else table[count].reshape(1, -1)
 
     def forward(self, y: torch.Tensor, phase: str, snr: float = None, gamma: float = None,
                 count: int = None) -> torch.Tensor:

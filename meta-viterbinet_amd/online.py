@@ -12,8 +12,9 @@ class OnlineTrainer:
     deep_learning_setup() creates (trainer.py:163-173), and runs `iterations` CE+Adam steps on one word on the GPU."""
 
     def __init__(self, detector, memory_length: int, lr: float = 0.001, betas=(0.9, 0.999), eps: float = 1e-8,
-                 train_minibatch_size: int = 32):
+                 train_minibatch_size: int = 32, use_kernel: bool = True):
         self.detector = detector
+        self.use_kernel = use_kernel  # False: online_training on stock PyTorch autograd (the cross-check of the kernel)
         self.memory_length = memory_length
         self.lr, self.betas, self.eps = lr, betas, eps
         self.train_minibatch_size = train_minibatch_size
@@ -107,6 +108,8 @@ class OnlineTrainer:
         full_word=True uses every sample each iteration (the Meta-ViterbiNet variant, metavnet_trainer.py:41-64)."""
         p = self.params
         dev = p[0].device
+        if p[5].numel() > 32 or not self.use_kernel:  # the one-launch kernel keeps parameters + both Adam moments in LDS: n_states <= 32
+            return self._online_training_autograd(tx, rx, iterations, batch_idx, full_word, return_loss)
         _lib.require_gpu_tensor(rx, "rx")
         _lib.require_gpu_tensor(p[0], "detector parameters")
         y = rx.detach().to(torch.float32).reshape(-1).contiguous()
@@ -132,3 +135,29 @@ class OnlineTrainer:
         _lib.check(rc, "mvn_vnet_online_train_f32")
         self.step += iterations
         return loss
+
+    def _online_training_autograd(self, tx, rx, iterations, batch_idx, full_word, return_loss):
+        """The same loop on stock PyTorch autograd (run_train_loop, trainer.py:492-505: forward 'train', CrossEntropy over the
+        selected samples, backward, Adam on the shared exp_avg / exp_avg_sq / step): the route for memory_length >= 6, whose
+        parameter set does not fit the training kernel's LDS image.  Same draws as the kernel path (select_batches)."""
+        import torch.nn.functional as F
+
+        p = self.params
+        dev = p[0].device
+        S = p[5].numel()
+        y = rx.detach().to(device=dev, dtype=torch.float32).reshape(1, -1)
+        T = y.shape[1]
+        labels = calculate_states(self.memory_length, tx.detach().to(dev).reshape(1, -1)).reshape(-1).long()
+        idx = None
+        if not full_word:
+            idx = (self.select_batches(T, iterations) if batch_idx is None else batch_idx.to(dev)).long()
+            if idx.shape[0] != iterations:
+                raise ValueError("batch_idx must be [iterations, M]")
+        losses = []
+        for it in range(iterations):
+            logits = self.detector(y, "train").reshape(-1, S)
+            loss = F.cross_entropy(logits, labels) if full_word else F.cross_entropy(logits[idx[it]], labels[idx[it]])
+            self.adam_step(torch.autograd.grad(loss, p))
+            if return_loss:
+                losses.append(loss.detach())
+        return torch.stack(losses).to(torch.float32) if return_loss else None

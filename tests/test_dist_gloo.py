@@ -67,6 +67,11 @@ def _coded_problem():
     return torch.tensor(msg), torch.tensor(y.astype(np.float32))
 
 
+def _replica_trial(i):
+    """stand-in for one eval_by_word trial: a deterministic ser_by_word[300] of trial i"""
+    return np.random.RandomState(100 + i).rand(300).astype(np.float32)
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -81,7 +86,9 @@ def _worker(rank, world, port, q):
         msg, cw_y = _coded_problem()
         _, _, c3 = mvn.sharded_eval(_oracle_detector(pri), msg, cw_y, 8.0, 0.2, None, counter=_oracle_counter, n_symbols=2,
                                     rs_decoder=_oracle_rs)
-        q.put((rank, counters.tolist(), c2.tolist(), ser, fer, c3.tolist()))
+        # replica mode (configs that do not shard within a trial): 5 trials over 2 ranks, one all_gather
+        rep = mvn.replica_eval(_replica_trial, 5)
+        q.put((rank, counters.tolist(), c2.tolist(), ser, fer, c3.tolist(), rep.tolist()))
     finally:
         dist.destroy_process_group()
 
@@ -107,7 +114,10 @@ def test_world2_counters_equal_single_process():
     _, _, coded1 = mvn.sharded_eval(_oracle_detector(pri), msg, cw_y, 8.0, 0.2, None, counter=_oracle_counter, n_symbols=2,
                                     rs_decoder=_oracle_rs, rank=0, world=1)
     assert coded1[1] == 21 * 24
-    for rank, counters, c2, ser, fer, c3 in res:
+    rep1 = mvn.replica_eval(_replica_trial, 5)  # no process group: every trial on this process
+    assert rep1.shape == (5, 300) and np.array_equal(rep1[3], _replica_trial(3))
+    for rank, counters, c2, ser, fer, c3, rep in res:
+        assert np.array_equal(np.asarray(rep, np.float32), rep1)  # same [trial, block] table on every rank
         assert counters == c1.tolist()  # identical integers on every rank
         assert c2 == call.tolist()
         assert (ser, fer) == (ser1, fer1)

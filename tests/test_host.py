@@ -140,3 +140,36 @@ def test_meta_train_loop_golden(golden, tag, maml):
     for i, p in enumerate(det.parameters()):
         assert np.allclose(p.detach().numpy(), g[f"{tag}_w1_{i}"], rtol=0, atol=1e-6), i
     assert tr.step == 4
+
+
+def test_online_training_falls_back_to_autograd_above_32_states():
+    """memory_length 6 (64 states): the parameter set does not fit the training kernel's LDS image, so
+    OnlineTrainer.online_training runs run_train_loop (trainer.py:492-505) on stock autograd -- same draws, same shared
+    Adam state -- instead of raising.  Checked against torch.optim.Adam on a copy (CPU tensors: no GPU needed)."""
+    import copy
+
+    import torch.nn.functional as F
+
+    L, S, T, iters = 6, 64, 96, 7
+    torch.manual_seed(3)
+    det = mvn.VNETDetector(S, {"train": T, "val": T}).to("cpu")
+    det.net.to("cpu")
+    ref = copy.deepcopy(det)
+    tx = torch.randint(0, 2, (1, T)).float()
+    rx = torch.randn(1, T)
+    tr = mvn.OnlineTrainer(det, L)
+    idx = tr.select_batches(T, iters)
+    loss = tr.online_training(tx, rx, iterations=iters, batch_idx=idx, return_loss=True)
+    opt = torch.optim.Adam(ref.parameters(), lr=0.001)
+    labels = mvn.calculate_states(L, tx).reshape(-1).long()
+    want = []
+    for it in range(iters):
+        out = ref(rx, "train").reshape(-1, S)
+        lo = F.cross_entropy(out[idx[it].long()], labels[idx[it].long()])
+        opt.zero_grad()
+        lo.backward()
+        opt.step()
+        want.append(float(lo))
+    assert tr.step == iters and np.allclose(loss.numpy(), want, rtol=1e-5)
+    for a, b in zip(det.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
