@@ -200,6 +200,18 @@ int mvn_isi_awgn_transmit(const float *bits, int64_t ld_bits, int32_t K, const v
                           int32_t L, mvn_stream_t stream);
 
 /*
+ * On-device word generator: the inner loop of ChannelModelDataset.get_snr_data for uncoded words
+ * (python_code/channel/channel_dataset.py:65-83: random bits, zero padding by L, BPSK (modulator.py:12),
+ * ISIAWGNChannel.transmit (channel.py:12-35)) fused in one kernel: bits ~ Bernoulli(1/2) and noise ~ N(0,1) from the
+ * counter-based Philox4x32-10 generator (a pure function of (seed, word, position): same DISTRIBUTION as the
+ * reference's two RandomState streams, not the same stream -- mvn_isi_awgn_transmit replays recorded draws bit for bit).
+ *   tx [B, tx_ld>=T] transmitted bits as fp32 {0.,1.} (NULL: not stored); y [B, y_ld>=T] received words;
+ *   h [Bh,L] float64 taps (row b % Bh for word b), sigma = 10^(-snr/20) (channel.py:23,31); L <= 16.
+ */
+int mvn_generate_words_f32(float *tx, int64_t tx_ld, float *y, int64_t y_ld, const double *h, int64_t Bh, double sigma,
+                           uint64_t seed, int64_t B, int32_t T, int32_t L, mvn_stream_t stream);
+
+/*
  * Reed-Solomon outer code, batched over words; bits are fp32 {0,1}, 8 per GF(2^8)
  * symbol, MSB first (np.packbits).  Same code and same behaviour past the correction capacity as
  * python_code/ecc/rs_main.py: encode (:9-18) / decode (:21-37) -- prim 0x11d, generator 2, nsym parity bytes,

@@ -88,3 +88,29 @@ def transmit(bits, h: np.ndarray, snr: float, memory_length: int, noise=None):
                                                _lib.current_stream(c.device))
     _lib.check(rc, "mvn_isi_awgn_transmit")
     return y
+
+
+def generate_words(n_words: int, block_length: int, h: np.ndarray, snr: float, memory_length: int, device, seed: int,
+                   want_tx: bool = True):
+    """Uncoded words generated ON the device in one launch (mvn_generate_words_f32): counterpart of the inner loop of
+    ChannelModelDataset.get_snr_data (channel_dataset.py:65-83) -- Bernoulli(1/2) bits, zero padding by L, BPSK, the
+    anti-causal ISI channel `h` [Bh,L] (row b % Bh for word b) and white noise of std 10^(-snr/20) -- with Philox
+    counter-based randomness (same distribution as the reference's RandomState streams, not the same stream).
+    Returns (tx [n,K] fp32 {0,1} or None, y [n,K] fp32)."""
+    import torch
+
+    from . import _lib
+
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.MvnError("generate_words runs on an MI355X (ROCm) device only")
+    hd = torch.as_tensor(np.ascontiguousarray(h, dtype=np.float64).reshape(-1, memory_length), device=dev)
+    y = torch.empty((n_words, block_length), dtype=torch.float32, device=dev)
+    tx = torch.empty((n_words, block_length), dtype=torch.float32, device=dev) if want_tx else None
+    sigma = (10 ** (snr / 10)) ** (-0.5)  # channel.py:23,31
+    with torch.cuda.device(dev):
+        rc = _lib.load().mvn_generate_words_f32(_lib.ptr(tx), block_length, _lib.ptr(y), block_length, _lib.ptr(hd), hd.shape[0],
+                                                float(sigma), int(seed) & 0xFFFFFFFFFFFFFFFF, n_words, block_length, memory_length,
+                                                _lib.current_stream(dev))
+    _lib.check(rc, "mvn_generate_words_f32")
+    return tx, y

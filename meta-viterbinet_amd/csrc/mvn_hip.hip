@@ -396,6 +396,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 #include "rs_codec.inc"
 #include "online_train.inc"
 #include "maml_train.inc"
+#include "word_gen.inc"
 
 // -------------------------------------------------------------------------------------------
 // metrics.py:7-17 as integer counters.  One wave per row, block-level reduction, one atomic
@@ -868,6 +869,17 @@ int mvn_isi_awgn_transmit(const float *bits, int64_t ld_bits, int32_t K, const v
     else
         hipLaunchKernelGGL((isi_awgn_kernel<float>), dim3(grid), dim3(256), 0, st, bits, ld_bits, K, (const float *)noise, h,
                            Bh, sigma, y, y_ld, B, T, L);
+    return (int)hipGetLastError();
+}
+
+int mvn_generate_words_f32(float *tx, int64_t tx_ld, float *y, int64_t y_ld, const double *h, int64_t Bh, double sigma,
+                           uint64_t seed, int64_t B, int32_t T, int32_t L, mvn_stream_t stream) {
+    if (B < 0 || T < 0 || L < 1 || L > 16 || y_ld < T || (tx && tx_ld < T) || Bh < 1) return MVN_E_DIMS;
+    if (B == 0 || T == 0) return MVN_OK;
+    if (!y || !h) return MVN_E_NULL;
+    const int64_t n = B * (int64_t)((T + 3) / 4);
+    hipLaunchKernelGGL(generate_words_kernel, dim3((unsigned)((n + kGenThreads - 1) / kGenThreads)), dim3(kGenThreads), 0,
+                       (hipStream_t)stream, tx, tx_ld, y, y_ld, h, Bh, sigma, (uint32_t)seed, (uint32_t)(seed >> 32), B, T, L);
     return (int)hipGetLastError();
 }
 

@@ -31,16 +31,22 @@ def data_indices(val_frames: int, subframes_in_frame: int) -> torch.Tensor:
 
 
 def synthetic_words(n_words: int, block_length: int, memory_length: int, snr: float, gamma: float,
-                    device, seed: int, channel_coefficients: str = "time_decay"):
+                    device, seed: int, channel_coefficients: str = "time_decay", fused: bool = True):
     """At-scale synthetic inputs generated on `device`: bits ~ Bernoulli(1/2), zero-padded by
     L, BPSK 1-2c, anti-causal ISI y[t] = sum_k h[L-1-k] s[t+k] + w[t] (channel.py:25-27), w ~ N(0, 10^(-snr/10)).
     Same distribution as ChannelModelDataset (channel_dataset.py:55-95), different RNG stream.
+    On a GPU the words come from ONE kernel (channel.generate_words: Philox bits + Box-Muller noise + the L-tap channel);
+    fused=False keeps the older route (ATen randint / randn + mvn_isi_awgn_transmit).
     Returns (tx [n,block_length] fp32 {0,1}, y [n,block_length] fp32)."""
+    L = memory_length
+    h = estimate_channel(L, gamma, channel_coefficients)
+    if fused and torch.device(device).type == "cuda":
+        from .channel import generate_words
+
+        return generate_words(n_words, block_length, h, snr, L, device, seed)
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    L = memory_length
     tx = torch.randint(0, 2, (n_words, block_length), generator=g, device=device, dtype=torch.int8).to(torch.float32)
-    h = estimate_channel(L, gamma, channel_coefficients)
     noise = torch.randn(n_words, block_length, generator=g, device=device)
     if torch.device(device).type == "cuda":
         return tx, transmit(tx, h, snr, L, noise)  # mvn_isi_awgn_transmit

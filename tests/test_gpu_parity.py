@@ -1132,3 +1132,64 @@ def test_config4_meta_viterbinet_reference_defaults(golden, dev):
     _compare_online_runs(s_k, n_k, s_t, n_t)
     frozen = mvn.eval_by_word(_vnet_with(w, 16, 136, dev), msg, rx, 10.0, 0.2, 2, 25)
     assert s_k.mean() <= frozen.mean()
+
+
+# ---------------------------------------------------------------- f#1: fused on-device word generator
+def _philox4x32_10(c, k):
+    """NumPy Philox4x32-10 (Salmon et al. 2011; Random123): c [n,4] uint32 counters, k (k0, k1) -> [n,4] uint32."""
+    c = c.astype(np.uint64)
+    k0, k1 = np.uint64(k[0]), np.uint64(k[1])
+    M0, M1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[:, 0], M1 * c[:, 2]
+        c = np.stack([(p1 >> np.uint64(32)) ^ c[:, 1] ^ k0, p1 & MASK, (p0 >> np.uint64(32)) ^ c[:, 3] ^ k1, p0 & MASK], axis=1)
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & MASK, (k1 + np.uint64(0xBB67AE85)) & MASK
+    return c.astype(np.uint32)
+
+
+def test_word_generator_bits_are_philox_and_noise_is_standard_normal(dev):
+    """mvn_generate_words_f32 (channel_dataset.py:65-83 + channel.py:12-35 in one kernel).  Integer part bit-exact: the
+    transmitted bits are Philox4x32-10 output (NumPy restatement checked against the Random123 known answers).  The
+    received words equal the replay kernel's noise-free output plus sigma * z with z ~ N(0,1): Kolmogorov-Smirnov against
+    the normal CDF, moments, and no correlation with the neighbour sample or the bits."""
+    import scipy.stats
+
+    kat = _philox4x32_10(np.array([[0, 0, 0, 0], [0xFFFFFFFF] * 4, [0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344]], np.uint32), (0, 0))
+    assert kat[0].tolist() == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert _philox4x32_10(np.array([[0xFFFFFFFF] * 4], np.uint32), (0xFFFFFFFF, 0xFFFFFFFF))[0].tolist() == \
+        [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert _philox4x32_10(np.array([[0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344]], np.uint32), (0xA4093822, 0x299F31D0))[0].tolist() == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    seed = 0x0123456789ABCDEF
+    for L, B, T in ((4, 37, 1000), (8, 5, 130), (2, 3, 127), (16, 4, 257), (4, 2, 1)):
+        h = np.exp(-0.2 * np.arange(L)).reshape(1, L) * np.array([[1.0], [0.9], [0.8]])  # three tap rows: word b uses b % 3
+        tx, y = mvn.generate_words(B, T, h, 9.0, L, dev, seed)
+        groups = (T + 127) // 128
+        ctr = np.array([[g, b, 0, 0] for b in range(B) for g in range(groups)], np.uint32)
+        words = _philox4x32_10(ctr, (seed & 0xFFFFFFFF, seed >> 32)).reshape(B, groups * 4)
+        bits = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(B, -1)[:, :T].astype(np.float32)
+        assert np.array_equal(_np(tx), bits), (L, B, T)
+        clean = mvn.transmit(tx, h, 9.0, L, None)
+        z = (_np(y).astype(np.float64) - _np(clean)) / (10 ** (9.0 / 10)) ** -0.5
+        assert np.all(np.abs(z) < 7.0)
+        tx2, y2 = mvn.generate_words(B, T, h, 9.0, L, dev, seed)
+        assert torch.equal(tx, tx2) and torch.equal(y, y2)  # a pure function of (seed, word, position)
+        assert not torch.equal(y, mvn.generate_words(B, T, h, 9.0, L, dev, seed + 1)[1])
+    B, T, L = 2000, 1000, 4
+    h = mvn.estimate_channel(L, 0.2, "time_decay")
+    tx, y = mvn.generate_words(B, T, h, 10.0, L, dev, 3450002)
+    z = ((_np(y).astype(np.float64) - _np(mvn.transmit(tx, h, 10.0, L, None))) / (10 ** (10.0 / 10)) ** -0.5)
+    n = z.size
+    assert abs(z.mean()) < 5 / np.sqrt(n) and abs(z.var() - 1) < 5 * np.sqrt(2 / n)
+    assert abs(scipy.stats.kurtosis(z.ravel())) < 5 * np.sqrt(24 / n) and abs(scipy.stats.skew(z.ravel())) < 5 * np.sqrt(6 / n)
+    assert scipy.stats.kstest(z.ravel()[:200000], "norm").pvalue > 1e-3
+    assert abs(np.mean(z[:, :-1] * z[:, 1:])) < 5 / np.sqrt(n) and abs(np.mean(z * (1 - 2 * _np(tx)))) < 5 / np.sqrt(n)
+    b = _np(tx)
+    assert abs(b.mean() - 0.5) < 5 * 0.5 / np.sqrt(n) and abs(np.mean((1 - 2 * b[:, :-1]) * (1 - 2 * b[:, 1:]))) < 5 / np.sqrt(n)
+    # same channel statistics as harness.synthetic_words' three-kernel route: VA symbol error rates agree within 5 sigma
+    va = mvn.VADetector(16, L, T, 1, "ISI_AWGN", 0, False, 1, {"train": "time_decay", "val": "time_decay"})
+    c1 = mvn.count_errors(va(y, "val", 10.0, 0.2), tx)
+    tx3, y3 = mvn.synthetic_words(B, T, L, 10.0, 0.2, dev, seed=11, fused=False)
+    c3 = mvn.count_errors(va(y3, "val", 10.0, 0.2), tx3)
+    p1, p3 = float(c1[0]) / n, float(c3[0]) / n
+    assert abs(p1 - p3) < 5 * np.sqrt((p1 + p3) / n), (p1, p3)
