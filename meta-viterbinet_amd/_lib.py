@@ -90,6 +90,38 @@ def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(device):
+    """`with on_device(t.device):` makes t's GPU current for a launch; free when it already is (the by-word evaluation
+    issues hundreds of B=1 calls, where torch.cuda.device()'s get/set pair is a measurable part of each)."""
+    import torch
+
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(idx)
+
+
+def f32c(t):
+    """t as a contiguous fp32 tensor; the tensor itself when it already is one (only its data_ptr is used: no autograd
+    bookkeeping is involved, so no detach())."""
+    import torch
+
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return t
+    return t.detach().to(torch.float32).contiguous()
+
+
 def require_gpu_tensor(t, name):
     if not t.is_cuda:
         raise MvnError(

@@ -818,15 +818,23 @@ int mvn_vnet_online_train_f32(const float *y, const int32_t *labels, int32_t T, 
     if (n_iter == 0) return MVN_OK;
     if (!y || !labels || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !adam_m || !adam_v) return MVN_E_NULL;
     const size_t lds = online_train_lds_bytes(S);
-    static size_t lds_allowed = 0;  // the opt-in to > 64 KB of dynamic LDS is per function, not per launch: raise it when needed
-    if (lds > lds_allowed) {
-        hipError_t e = hipFuncSetAttribute((const void *)online_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        lds_allowed = lds;
-    }
-    hipLaunchKernelGGL(online_train_kernel, dim3(1), dim3(kTrainThreads), lds, (hipStream_t)stream, y, labels, T, batch_idx,
-                       M, n_iter, W1, b1, W2, b2, W3, b3, adam_m, adam_v, pow((double)beta1, (double)step0),
-                       pow((double)beta2, (double)step0), lr, beta1, beta2, eps, loss_out, S, (int)online_train_lds_floats(S));
+    static size_t lds_allowed[3] = {0, 0, 0};  // the opt-in to > 64 KB of dynamic LDS is per function: raise it when needed
+#define MVN_ONLINE_LAUNCH(SC, SLOT)                                                                                        \
+    do {                                                                                                                   \
+        if (lds > lds_allowed[SLOT]) {                                                                                     \
+            hipError_t e = hipFuncSetAttribute((const void *)online_train_kernel<SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return (int)e;                                                                            \
+            lds_allowed[SLOT] = lds;                                                                                       \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(online_train_kernel<SC>, dim3(1), dim3(kTrainThreads), lds, (hipStream_t)stream, y, labels, T,   \
+                           batch_idx, M, n_iter, W1, b1, W2, b2, W3, b3, adam_m, adam_v, pow((double)beta1, (double)step0), \
+                           pow((double)beta2, (double)step0), lr, beta1, beta2, eps, loss_out, S,                           \
+                           (int)online_train_lds_floats(S));                                                               \
+    } while (0)
+    if (S == 16) MVN_ONLINE_LAUNCH(16, 0);
+    else if (S == 32) MVN_ONLINE_LAUNCH(32, 1);
+    else MVN_ONLINE_LAUNCH(0, 2);
+#undef MVN_ONLINE_LAUNCH
     return (int)hipGetLastError();
 }
 
@@ -841,16 +849,23 @@ int mvn_vnet_maml_train_f32(const float *rx_words, const int32_t *labels, int32_
     if (!rx_words || !labels || !support_idx || !query_idx || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !adam_m || !adam_v)
         return MVN_E_NULL;
     const size_t lds = maml_train_lds_floats(S) * sizeof(float);
-    static size_t lds_allowed = 0;
-    if (lds > lds_allowed) {
-        hipError_t e = hipFuncSetAttribute((const void *)maml_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        lds_allowed = lds;
-    }
-    hipLaunchKernelGGL(maml_train_kernel, dim3(1), dim3(kTrainThreads), lds, (hipStream_t)stream, rx_words, labels, T,
-                       support_idx, W, query_idx, n_steps, W1, b1, W2, b2, W3, b3, adam_m, adam_v,
-                       pow((double)beta1, (double)step0), pow((double)beta2, (double)step0), meta_lr, second_order, lr, beta1,
-                       beta2, eps, loss_out, S, (int)maml_train_lds_floats(S));
+    static size_t lds_allowed[3] = {0, 0, 0};
+#define MVN_MAML_LAUNCH(SC, SLOT)                                                                                          \
+    do {                                                                                                                   \
+        if (lds > lds_allowed[SLOT]) {                                                                                     \
+            hipError_t e = hipFuncSetAttribute((const void *)maml_train_kernel<SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return (int)e;                                                                            \
+            lds_allowed[SLOT] = lds;                                                                                       \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(maml_train_kernel<SC>, dim3(1), dim3(kTrainThreads), lds, (hipStream_t)stream, rx_words, labels, T, \
+                           support_idx, W, query_idx, n_steps, W1, b1, W2, b2, W3, b3, adam_m, adam_v,                     \
+                           pow((double)beta1, (double)step0), pow((double)beta2, (double)step0), meta_lr, second_order, lr, \
+                           beta1, beta2, eps, loss_out, S, (int)maml_train_lds_floats(S));                                 \
+    } while (0)
+    if (S == 16) MVN_MAML_LAUNCH(16, 0);
+    else if (S == 32) MVN_MAML_LAUNCH(32, 1);
+    else MVN_MAML_LAUNCH(0, 2);
+#undef MVN_MAML_LAUNCH
     return (int)hipGetLastError();
 }
 

@@ -22,11 +22,7 @@ def _default_device():
     return torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 
-def _as_f32(t: torch.Tensor) -> torch.Tensor:
-    t = t.detach()
-    if t.dtype != torch.float32:
-        t = t.to(torch.float32)
-    return t.contiguous()
+_as_f32 = _lib.f32c
 
 
 def _new_decisions(y: torch.Tensor, T: int) -> torch.Tensor:
@@ -123,11 +119,20 @@ class VADetector(nn.Module):
                                "at non-singleton dimension 0")
         _check_T(T, yc)
         decoded_word = _new_decisions(yc, T)
-        with torch.cuda.device(yc.device):
+        with _lib.on_device(yc.device):
             rc = _lib.load().mvn_va_decode_f32(_lib.ptr(yc), Ty, _lib.ptr(pri), W, _lib.ptr(decoded_word), Ty,
                                                None, B, T, self.n_states, _lib.current_stream(yc.device))
         _lib.check(rc, "mvn_va_decode_f32")
         return decoded_word
+
+
+def _weights_on(params, device, n_states):
+    w = [_as_f32(p) if p.device == device else _as_f32(p).to(device) for p in params]
+    if (len(w) != 6 or w[0].shape != (HIDDEN1_SIZE, 1) or w[1].shape != (HIDDEN1_SIZE,) or w[2].shape != (HIDDEN2_SIZE, HIDDEN1_SIZE)
+            or w[3].shape != (HIDDEN2_SIZE,) or w[4].shape != (n_states, HIDDEN2_SIZE) or w[5].shape != (n_states,)):
+        shapes = [(HIDDEN1_SIZE, 1), (HIDDEN1_SIZE,), (HIDDEN2_SIZE, HIDDEN1_SIZE), (HIDDEN2_SIZE,), (n_states, HIDDEN2_SIZE), (n_states,)]
+        raise ValueError(f"ViterbiNet parameter shapes {[tuple(t.shape) for t in w]} != {shapes}")
+    return w
 
 
 def _vnet_val(y: torch.Tensor, params, n_states: int, T: int, return_logits: bool = False):
@@ -136,11 +141,7 @@ def _vnet_val(y: torch.Tensor, params, n_states: int, T: int, return_logits: boo
     yc = _as_f32(y)
     B, Ty = yc.shape
     _check_T(T, yc)
-    w = [_as_f32(p).to(yc.device) for p in params]  # read at call time, never cached (python_utils.py:17-27)
-    shapes = [(HIDDEN1_SIZE, 1), (HIDDEN1_SIZE,), (HIDDEN2_SIZE, HIDDEN1_SIZE), (HIDDEN2_SIZE,),
-              (n_states, HIDDEN2_SIZE), (n_states,)]
-    if [tuple(t.shape) for t in w] != shapes:
-        raise ValueError(f"ViterbiNet parameter shapes {[tuple(t.shape) for t in w]} != {shapes}")
+    w = _weights_on(params, yc.device, n_states)  # read at call time, never cached (python_utils.py:17-27)
     lib = _lib.load()
     decoded_word = _new_decisions(yc, T)
     logits = torch.empty((B, T, n_states), dtype=torch.float32, device=yc.device) if return_logits else None
@@ -150,7 +151,7 @@ def _vnet_val(y: torch.Tensor, params, n_states: int, T: int, return_logits: boo
         if ws_bytes:  # 0: the fused 16-state kernel needs no scratch
             ws_bytes = max(ws_bytes, T * n_states * 4)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=yc.device)
-    with torch.cuda.device(yc.device):
+    with _lib.on_device(yc.device):
         rc = lib.mvn_vnet_decode_f32(_lib.ptr(yc), Ty, *[_lib.ptr(t) for t in w], _lib.ptr(decoded_word), Ty,
                                      _lib.ptr(logits), None, _lib.ptr(ws), ws_bytes, B, T, n_states,
                                      _lib.current_stream(yc.device))
@@ -166,7 +167,7 @@ def _vnet_val_count(y, params, n_states, T, tx, rows=None, counters=None, return
     yc = _as_f32(y)
     B, Ty = yc.shape
     _check_T(T, yc)
-    w = [_as_f32(p).to(yc.device) for p in params]
+    w = _weights_on(params, yc.device, n_states)
     txc = _as_f32(tx).to(yc.device)
     if txc.shape[0] != B or txc.shape[1] > T:
         raise ValueError("tx must be [B, K<=T]")
@@ -177,7 +178,7 @@ def _vnet_val_count(y, params, n_states, T, tx, rows=None, counters=None, return
         mask = torch.zeros(B, dtype=torch.uint8, device=yc.device)
         mask[rows.to(yc.device)] = 1
     dec = torch.zeros(yc.shape, dtype=torch.float32, device=yc.device) if return_decisions else None
-    with torch.cuda.device(yc.device):
+    with _lib.on_device(yc.device):
         rc = _lib.load().mvn_vnet_decode_count_f32(_lib.ptr(yc), Ty, *[_lib.ptr(t) for t in w], _lib.ptr(txc),
                                                    txc.stride(0), txc.shape[1], _lib.ptr(mask), _lib.ptr(counters),
                                                    _lib.ptr(dec), Ty, B, T, n_states, _lib.current_stream(yc.device))
@@ -202,16 +203,26 @@ class VNETDetector(nn.Module):
                   nn.Linear(HIDDEN2_SIZE, self.n_states)]
         self.net = nn.Sequential(*layers).to(_default_device())
 
+    def _params(self):
+        """The six Parameter OBJECTS in parameters() order, looked up once per `net` (walking the module tree costs more
+        than a B=1 launch); their storage is still read at call time -- copy_model / load_state_dict / optimizers write
+        through the same objects."""
+        c = self.__dict__.get("_param_cache")
+        if c is None or c[0] is not self.net:
+            c = (self.net, list(self.net.parameters()))
+            self.__dict__["_param_cache"] = c
+        return c[1]
+
     def forward(self, y: torch.Tensor, phase: str, snr: float = None, gamma: float = None,
                 count: int = None) -> torch.Tensor:
         """'val' -> detected words [B,T]; otherwise the logits [B,T,S] with autograd (vnet_detector.py:35-63)."""
         if phase == "val":
-            return _vnet_val(y, list(self.net.parameters()), self.n_states, self.transmission_lengths["val"])
+            return _vnet_val(y, self._params(), self.n_states, self.transmission_lengths["val"])
         return self.net(y.reshape(-1, 1)).reshape(y.shape[0], y.shape[1], self.n_states)
 
     def val_count(self, y, tx, rows=None, counters=None, return_decisions=False):
         """forward(y,'val') + calculate_error_rates fused in one launch (16 states); see _vnet_val_count."""
-        return _vnet_val_count(y, list(self.net.parameters()), self.n_states, self.transmission_lengths["val"], tx, rows,
+        return _vnet_val_count(y, self._params(), self.n_states, self.transmission_lengths["val"], tx, rows,
                                counters, return_decisions)
 
     @torch.no_grad()
@@ -221,7 +232,7 @@ class VNETDetector(nn.Module):
         yc = _as_f32(y).reshape(-1)
         w = [_as_f32(p).to(yc.device) for p in self.net.parameters()]
         out = torch.empty((yc.numel(), self.n_states), dtype=torch.float32, device=yc.device)
-        with torch.cuda.device(yc.device):
+        with _lib.on_device(yc.device):
             rc = _lib.load().mvn_vnet_logits_f32(_lib.ptr(yc), *[_lib.ptr(t) for t in w], _lib.ptr(out),
                                                  yc.numel(), self.n_states, _lib.current_stream(yc.device))
         _lib.check(rc, "mvn_vnet_logits_f32")

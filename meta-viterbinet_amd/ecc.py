@@ -8,7 +8,8 @@ from . import _lib
 
 def _bits(t: torch.Tensor) -> torch.Tensor:
     _lib.require_gpu_tensor(t, "bits")
-    t = t.detach().to(torch.float32)
+    if t.dtype is not torch.float32:
+        t = t.detach().to(torch.float32)
     if t.dim() == 1:
         t = t.reshape(1, -1)
     return t if t.stride(-1) == 1 else t.contiguous()
@@ -25,7 +26,7 @@ def rs_decode(detected_words: torch.Tensor, n_symbols: int, return_status: bool 
         raise ValueError("Message is too long (%i when max is 255)" % (N // 8))
     out = torch.empty((B, N - 8 * n_symbols), dtype=torch.float32, device=rx.device)
     status = torch.empty(B, dtype=torch.int32, device=rx.device) if return_status else None
-    with torch.cuda.device(rx.device):
+    with _lib.on_device(rx.device):
         rc = _lib.load().mvn_rs_decode_bits_f32(_lib.ptr(rx), rx.stride(0), _lib.ptr(out), out.stride(0), _lib.ptr(status), B,
                                                 N, n_symbols, _lib.current_stream(rx.device))
     _lib.check(rc, "mvn_rs_decode_bits_f32")
@@ -41,7 +42,7 @@ def rs_encode(words: torch.Tensor, n_symbols: int) -> torch.Tensor:
     if K // 8 + n_symbols > 255:
         raise ValueError("Message is too long (%i when max is 255)" % (K // 8 + n_symbols))
     out = torch.empty((B, K + 8 * n_symbols), dtype=torch.float32, device=msg.device)
-    with torch.cuda.device(msg.device):
+    with _lib.on_device(msg.device):
         rc = _lib.load().mvn_rs_encode_bits_f32(_lib.ptr(msg), msg.stride(0), _lib.ptr(out), out.stride(0), B, K, n_symbols,
                                                 _lib.current_stream(msg.device))
     _lib.check(rc, "mvn_rs_encode_bits_f32")

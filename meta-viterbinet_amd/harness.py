@@ -202,17 +202,16 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
         # No update runs between blocks, so nothing on the host depends on a block's ser: the reference's 300 B=1 detector
         # calls are issued exactly like it issues them, but the per-block ser stays on the device and ONE transfer ends the
         # run (the reference synchronises after every block, trainer.py:305).
-        sers = []
+        counters = torch.zeros((N, 4), dtype=torch.int64, device=rx.device)  # row k: {bit errors, bits, ...} of block k
         for count in range(N):
             if count % subframes_in_frame == 0:
                 continue  # pilot block: ser 0, nothing to decode (its detection only feeds the buffer of the update branches)
-            received_word = rx[count].reshape(1, -1)
+            received_word = rx[count:count + 1]
             detected_word = detector(received_word, "val", snr, gamma, count) if pass_count else detector(received_word, "val", snr, gamma)
-            decoded_word = rs_decode(detected_word, n_symbols)
-            sers.append((count, (decoded_word != tx[count].reshape(1, -1)).float().mean()))
-        if sers:
-            vals = torch.stack([v for _, v in sers]).cpu().numpy()
-            ser_by_word[[c for c, _ in sers]] = vals
+            _metrics.count_errors(rs_decode(detected_word, n_symbols), tx[count:count + 1], None, counters[count])
+        c = counters.cpu().numpy()
+        data = c[:, 1] > 0
+        ser_by_word[data] = (c[data, 0] / c[data, 1]).astype(np.float32)  # the reference's fp32 mean (metrics.py:13)
         return ser_by_word
     if (self_supervised or online_meta) and online_trainer is None:
         raise ValueError("self_supervised / online_meta need an OnlineTrainer (it owns the Adam state)")

@@ -11,8 +11,8 @@ def count_errors(prediction: torch.Tensor, target: torch.Tensor, rows: torch.Ten
     """Accumulates int64[4] = {bit_errors, bits, frame_errors, frames} over `rows` (default: all rows)
     on the device; no host sync.  These are the counters the multi-GPU all-reduce carries."""
     _lib.require_gpu_tensor(prediction, "prediction")
-    p = prediction.detach().to(torch.float32)
-    t = target.detach().to(device=p.device, dtype=torch.float32)
+    p = prediction if prediction.dtype is torch.float32 else prediction.detach().to(torch.float32)
+    t = target if (target.dtype is torch.float32 and target.device == p.device) else target.detach().to(device=p.device, dtype=torch.float32)
     if p.stride(-1) != 1:
         p = p.contiguous()
     if t.stride(-1) != 1:
@@ -24,7 +24,7 @@ def count_errors(prediction: torch.Tensor, target: torch.Tensor, rows: torch.Ten
         counters = torch.zeros(4, dtype=torch.int64, device=p.device)
     r = None if rows is None else rows.to(device=p.device, dtype=torch.int64).contiguous()
     n = p.shape[0] if r is None else r.numel()
-    with torch.cuda.device(p.device):
+    with _lib.on_device(p.device):
         rc = _lib.load().mvn_count_errors(_lib.ptr(p), p.stride(0), _lib.ptr(t), t.stride(0), _lib.ptr(r), n,
                                           p.shape[1], _lib.ptr(counters), _lib.current_stream(p.device))
     _lib.check(rc, "mvn_count_errors")
