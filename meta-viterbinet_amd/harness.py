@@ -178,9 +178,10 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
                  verbose: bool = False, online_meta: bool = False, meta_detector=None, meta_lr: float = 0.1,
                  MAML: bool = True, window_size: int = 1, meta_train_iterations: int = 20, meta_j_num: int = 10,
                  meta_subframes: int = 5, meta_style_online_training: bool = False,
-                 graphed_meta: bool = True, hip_meta: bool = True) -> np.ndarray:
-    """Sequential per-block online evaluation: counterpart of Trainer.eval_by_word (trainer.py:267-354) with
-    buffer_empty=True and weights_init='last_frame'.  Everything but the control flow stays on the GPU:
+                 graphed_meta: bool = True, hip_meta: bool = True, initial_buffer=None, weights_init: str = "last_frame",
+                 meta_training_weights=None) -> np.ndarray:
+    """Sequential per-block online evaluation: counterpart of Trainer.eval_by_word (trainer.py:267-354).  Everything but the
+    control flow stays on the GPU:
         for every block k:  detect (B=1)  ->  data block: RS decode, ser, RS re-encode | pilot: encode the known word
             ->  if ser <= ser_thresh: buffer (rx, label), label = detected word if ser > 0 else the re-encoded word
             ->  if online_meta and k % meta_subframes == 0 (k >= meta_subframes, buffer > 2): restart from the saved
@@ -189,6 +190,11 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
             ->  if self_supervised (and ser <= ser_thresh): online_trainer.online_training(last buffered pair) (:345-347);
                 meta_style_online_training=True first restores the saved weights and trains on the whole word
                 (metavnet_trainer.py:52-64), otherwise a 32-sample minibatch per iteration (vnet_trainer.py:49-60).
+    initial_buffer = (tx_codewords [W, T], rx_words [W, T]): the reference's buffer_empty=False (:278-286) -- the buffer
+    starts with W words drawn from the training channel and stays W long (every qualifying block pushes the oldest out,
+    :325-328); None = buffer_empty=True.  weights_init (meta_weights_init, :356-366): what a meta update restarts from --
+    'last_frame' the weights saved after the previous update, 'random' freshly initialised weights and a fresh optimizer,
+    'meta_training' the weights in `meta_training_weights` (the reference loads its meta-trained checkpoint).
     tx [N, K] message bits, rx [N, K + 8*n_symbols] received words; block k is a pilot when k % subframes_in_frame == 0
     (trainer.py:100-102).  Returns ser_by_word [N] (0 for pilots), like the reference.
     One host sync per block (the ser decides what happens next), as in the reference (trainer.py:305)."""
@@ -215,14 +221,24 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
         return ser_by_word
     if (self_supervised or online_meta) and online_trainer is None:
         raise ValueError("self_supervised / online_meta need an OnlineTrainer (it owns the Adam state)")
+    if weights_init not in ("last_frame", "random", "meta_training"):
+        raise ValueError("No such weights init!!!")
+    if weights_init == "meta_training" and meta_training_weights is None:
+        raise ValueError("weights_init='meta_training' needs meta_training_weights (six arrays in parameters() order)")
     if online_meta and meta_detector is None:
         raise ValueError("online_meta needs a META_VNETDetector")
     saved_detector = copy.deepcopy(detector) if (online_meta or meta_style_online_training) else None  # :275
-    buffer_rx = torch.empty([0, rx.shape[1]], device=rx.device)
-    buffer_tx = torch.empty([0, rx.shape[1]], device=rx.device)
+    buffer_empty = initial_buffer is None
+    if buffer_empty:
+        buffer_rx = torch.empty([0, rx.shape[1]], device=rx.device)
+        buffer_tx = torch.empty([0, rx.shape[1]], device=rx.device)
+    else:
+        buffer_tx, buffer_rx = [t.to(device=rx.device, dtype=torch.float32) for t in initial_buffer]
     meta_step = None  # meta.GraphedMetaStep, built at the first meta update (graphed_meta and a CUDA detector)
-    graphed_meta = graphed_meta and rx.is_cuda
-    hip_meta = hip_meta and rx.is_cuda and detector.n_states <= 32  # mvn_vnet_maml_train_f32 (the LDS holds 4 parameter vectors)
+    graphed_meta = graphed_meta and rx.is_cuda and (online_trainer is None or online_trainer.optimizer_type == "Adam")  # captured Adam update
+    # mvn_vnet_maml_train_f32: the LDS holds 4 parameter vectors (n_states <= 32); the kernel's optimizer is Adam
+    hip_meta = (hip_meta and rx.is_cuda and detector.n_states <= 32 and online_trainer is not None
+                and online_trainer.optimizer_type == "Adam" and online_trainer.use_kernel)
     support_idx = torch.arange(-window_size - 1, -1, device=rx.device).long()  # :288
     query_idx = -1 * torch.ones(1, device=rx.device).long()
     for count in range(N):
@@ -241,8 +257,20 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
         if ser <= ser_thresh:  # :319-329 (buffer_empty=True: the buffer only grows)
             buffer_rx = torch.cat([buffer_rx, received_word])
             buffer_tx = torch.cat([buffer_tx, detected_word.reshape(1, -1) if ser > 0 else encoded_word.reshape(1, -1)], dim=0)
+            if not buffer_empty:  # fixed-length window: the oldest word leaves (:325-328)
+                buffer_rx, buffer_tx = buffer_rx[1:], buffer_tx[1:]
         if online_meta and count % meta_subframes == 0 and count >= meta_subframes and buffer_rx.shape[0] > 2:  # :331-343
-            copy_model(source_model=saved_detector, dest_model=detector)  # weights_init == 'last_frame' (:360-361)
+            if weights_init == "last_frame":  # meta_weights_init (:356-366)
+                copy_model(source_model=saved_detector, dest_model=detector)
+            elif weights_init == "random":
+                for m in detector.net:
+                    if hasattr(m, "reset_parameters"):
+                        m.reset_parameters()
+                online_trainer.reset_state()
+            else:
+                with torch.no_grad():
+                    for p_, w_ in zip(detector.parameters(), meta_training_weights):
+                        p_.copy_(torch.as_tensor(w_, dtype=p_.dtype))
             if hip_meta:  # every MAML step of this update in ONE launch of the meta-learning kernel
                 sup, qry = [], []
                 for _ in range(meta_train_iterations):

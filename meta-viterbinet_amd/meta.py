@@ -34,7 +34,7 @@ def meta_train_loop(detector, meta_detector, online_trainer, received_words: tor
     soft_query = meta_detector(query_rx, "train", updated)
     loss_query = states_loss(soft_query, query_tx, online_trainer.memory_length)
     meta_grad = torch.autograd.grad(loss_query, params, create_graph=False)
-    online_trainer.adam_step(meta_grad)
+    online_trainer.optimizer_step(meta_grad)  # the trainer's single optimizer (trainer.py:452)
     return loss_query.detach()
 
 

@@ -12,9 +12,14 @@ class OnlineTrainer:
     deep_learning_setup() creates (trainer.py:163-173), and runs `iterations` CE+Adam steps on one word on the GPU."""
 
     def __init__(self, detector, memory_length: int, lr: float = 0.001, betas=(0.9, 0.999), eps: float = 1e-8,
-                 train_minibatch_size: int = 32, use_kernel: bool = True):
+                 train_minibatch_size: int = 32, use_kernel: bool = True, optimizer_type: str = "Adam"):
+        if optimizer_type not in ("Adam", "RMSprop", "SGD"):  # deep_learning_setup (trainer.py:163-175)
+            raise NotImplementedError("No such optimizer implemented!!!")
         self.detector = detector
-        self.use_kernel = use_kernel  # False: online_training on stock PyTorch autograd (the cross-check of the kernel)
+        self.optimizer_type = optimizer_type
+        # False: online_training on stock PyTorch autograd (the cross-check of the kernel).  The one-launch kernels implement
+        # the reference's default, Adam (config.yaml:35); RMSprop and SGD run on the autograd route.
+        self.use_kernel = use_kernel and optimizer_type == "Adam"
         self.memory_length = memory_length
         self.lr, self.betas, self.eps = lr, betas, eps
         self.train_minibatch_size = train_minibatch_size
@@ -24,6 +29,30 @@ class OnlineTrainer:
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step = 0
+
+    def reset_state(self):
+        """A fresh optimizer, like the deep_learning_setup() call of meta_weights_init('random') (trainer.py:356-359)."""
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.step = 0
+
+    @torch.no_grad()
+    def optimizer_step(self, grads):
+        """One step of the configured optimizer (torch.optim defaults, as deep_learning_setup builds them) from a list of
+        gradients: Adam (shared with the kernels), RMSprop (alpha 0.99, eps 1e-8, square average kept in exp_avg_sq) or SGD."""
+        if self.optimizer_type == "Adam":
+            return self.adam_step(grads)
+        self.step += 1
+        off = 0
+        for p, g in zip(self.params, grads):
+            n = p.numel()
+            if self.optimizer_type == "SGD":
+                p.data.add_(g, alpha=-self.lr)
+            else:
+                v = self.exp_avg_sq[off:off + n].view_as(p)
+                v.mul_(0.99).addcmul_(g, g, value=0.01)
+                p.data.addcdiv_(g, v.sqrt().add_(1e-8), value=-self.lr)
+            off += n
 
     @torch.no_grad()
     def adam_step(self, grads):
@@ -157,7 +186,7 @@ class OnlineTrainer:
         for it in range(iterations):
             logits = self.detector(y, "train").reshape(-1, S)
             loss = F.cross_entropy(logits, labels) if full_word else F.cross_entropy(logits[idx[it]], labels[idx[it]])
-            self.adam_step(torch.autograd.grad(loss, p))
+            self.optimizer_step(torch.autograd.grad(loss, p))
             if return_loss:
                 losses.append(loss.detach())
         return torch.stack(losses).to(torch.float32) if return_loss else None

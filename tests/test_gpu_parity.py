@@ -1193,3 +1193,33 @@ def test_word_generator_bits_are_philox_and_noise_is_standard_normal(dev):
     c3 = mvn.count_errors(va(y3, "val", 10.0, 0.2), tx3)
     p1, p3 = float(c1[0]) / n, float(c3[0]) / n
     assert abs(p1 - p3) < 5 * np.sqrt((p1 + p3) / n), (p1, p3)
+
+
+def test_eval_by_word_buffer_and_weights_init_variants(golden, dev):
+    """The remaining switches of Trainer.eval_by_word: buffer_empty=False (a fixed-length window that starts with words of
+    the training channel, trainer.py:278-286,325-328), weights_init in {'random', 'meta_training'} (meta_weights_init,
+    :356-366) and the RMSprop / SGD optimizers of deep_learning_setup (:163-175, autograd route)."""
+    g7 = golden("g7_by_word")
+    w = [g7[f"w{i}"] for i in range(6)]
+    msg, rx = _by_word_words(dev, "time_decay", 10.0, 3, N=40)
+    tmsg, trx = _by_word_words(dev, "time_decay", 10.0, 4, N=6)
+    init = (mvn.rs_encode(tmsg, 2), trx)  # the train draw, RS-encoded like trainer.py:283-286
+    meta = mvn.META_VNETDetector(16, {"train": 136, "val": 136})
+    common = dict(self_supervised=True, self_supervised_iterations=20, online_meta=True, meta_detector=meta, meta_train_iterations=2,
+                  meta_j_num=4, meta_subframes=5, meta_style_online_training=True)
+    seen = {}
+    for tag, kw, opt in (("window", dict(initial_buffer=init), "Adam"), ("random", dict(weights_init="random"), "Adam"),
+                         ("meta_training", dict(weights_init="meta_training", meta_training_weights=w), "Adam"),
+                         ("rmsprop", {}, "RMSprop"), ("sgd", dict(hip_meta=False), "SGD")):
+        det = _vnet_with(w, 16, 136, dev)
+        tr = mvn.OnlineTrainer(det, 4, optimizer_type=opt)
+        torch.manual_seed(2)
+        ser = mvn.eval_by_word(det, msg, rx, 10.0, 0.2, 2, 25, online_trainer=tr, **common, **kw)
+        assert ser.shape == (40,) and np.all(np.isfinite(ser)) and ser[0] == 0 and ser[25] == 0  # pilots
+        assert tr.step > 0 and all(torch.isfinite(p).all() for p in det.parameters())
+        seen[tag] = [p.detach().clone() for p in det.parameters()]
+    assert not torch.equal(seen["random"][2], seen["meta_training"][2])  # different restart points, different weights
+    assert not torch.equal(seen["rmsprop"][2], seen["sgd"][2])
+    with pytest.raises(ValueError):
+        mvn.eval_by_word(_vnet_with(w, 16, 136, dev), msg, rx, 10.0, 0.2, 2, 25, self_supervised=True,
+                         online_trainer=mvn.OnlineTrainer(_vnet_with(w, 16, 136, dev), 4), weights_init="nope")

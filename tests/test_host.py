@@ -173,3 +173,27 @@ def test_online_training_falls_back_to_autograd_above_32_states():
     assert tr.step == iters and np.allclose(loss.numpy(), want, rtol=1e-5)
     for a, b in zip(det.parameters(), ref.parameters()):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("opt", ["RMSprop", "SGD", "Adam"])
+def test_optimizer_variants_match_torch_optim(opt):
+    """deep_learning_setup's three optimizers (trainer.py:163-175): OnlineTrainer.optimizer_step against torch.optim with
+    its defaults, three steps on random gradients (CPU tensors)."""
+    import copy
+
+    torch.manual_seed(4)
+    det = mvn.VNETDetector(16, {"train": 8, "val": 8}).to("cpu")
+    det.net.to("cpu")
+    ref = copy.deepcopy(det)
+    tr = mvn.OnlineTrainer(det, 4, optimizer_type=opt)
+    o = {"RMSprop": torch.optim.RMSprop, "SGD": torch.optim.SGD, "Adam": torch.optim.Adam}[opt](ref.parameters(), lr=0.001)
+    for _ in range(3):
+        grads = [torch.randn_like(p) for p in det.parameters()]
+        tr.optimizer_step(grads)
+        for p, g in zip(ref.parameters(), grads):
+            p.grad = g.clone()
+        o.step()
+    for a, b in zip(det.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        mvn.OnlineTrainer(det, 4, optimizer_type="Adagrad")
