@@ -72,7 +72,7 @@ def event_time_ms(fn, iters, stream_device):
     (the ABI is called with torch's current stream, so torch.cuda.Event brackets exactly those launches)."""
     start = torch.cuda.Event(enable_timing=True)
     stop = torch.cuda.Event(enable_timing=True)
-    for _ in range(5):  # warm: first launches of a variant pay cache / clock ramp effects
+    for _ in range(5):  # warm: first launches of a variant pay cache effects; after idle stretches also the clock ramp
         fn()
     torch.cuda.synchronize(stream_device)
     start.record()
@@ -335,8 +335,8 @@ def self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--blocks", type=int, default=10000, help="blocks per GPU (BASELINE configs[1]: 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config entries (BASELINE configs[0],[2],[3],[4])")
@@ -390,6 +390,13 @@ def main():
         dec = det(y, "val", SNR_DB, GAMMA)
         mvn.count_errors(dec, tx, None, counters)
 
+    # The GPU's clock / power state settles over ~30 ms of sustained load (tools/time_ramp.py: the first 20 launches of the
+    # fused kernel run 1.52 ms, every later one 1.37): bring the device to its sustained state first, so that the W warm-up
+    # and K timed steps below measure the same machine whatever W is.  Untimed, bounded (60 ms).
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < 0.06:
+        step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     if world > 1:
