@@ -531,12 +531,9 @@ int launch_vnet16_fused(const float *y, int64_t y_ld, const float *W1, const flo
                         const unsigned char *row_mask, unsigned long long *counters, hipStream_t st) {
     const int nt = fusedn_tiles();  // NT = 2 runs 5 waves/SIMD (default); NT = 4 is the 64-symbol form, kept as a cross-check
     const unsigned gridn = (unsigned)((B + kFusedNWaves - 1) / kFusedNWaves);
-    // blocks of the last round of wave slots (256 CUs x workgroups per CU x 4 waves): see the kernel's priority note
-    const char *fe = getenv("MVN_FUSEDN_FINAL");
-    const int64_t final_blocks = fe ? atoll(fe) : 256 * (int64_t)(nt == 2 ? MVN_FN_WGS * kFusedNWaves : 16);
 #define MVN_FUSEDN_LAUNCH(WL, NT)                                                                                      \
     hipLaunchKernelGGL((vnet16_fusedn_kernel<WL, NT>), dim3(gridn), dim3(64 * kFusedNWaves), 0, st, y, y_ld, W1, b1, W2, b2, \
-                       W3, b3, dec, dec_ld, logits_out, final_metric, B, T, tx, tx_ld, K, row_mask, counters, final_blocks)
+                       W3, b3, dec, dec_ld, logits_out, final_metric, B, T, tx, tx_ld, K, row_mask, counters)
     if (nt == 2) {
         if (logits_out) MVN_FUSEDN_LAUNCH(true, 2); else MVN_FUSEDN_LAUNCH(false, 2);
     } else {

@@ -45,14 +45,10 @@ VARIANTS = {
 # variants that only differ by -D switches of the product source
 DEFS = {
     "fn_clock": ["-DMVN_DIAG_STAMPS"],  # wave timeline stamps (see vnet16_fusedn.inc)
-    "fn_wg4": ["-DMVN_FN_WGS=4"], "fn_wg5": ["-DMVN_FN_WGS=5"], "fn_wg6": ["-DMVN_FN_WGS=6"],
+    "fn_w4g5": ["-DMVN_FN_WAVES=4", "-DMVN_FN_WGS=5"],
     "fn_nt4": ["-DMVN_FUSEDN_DEFAULT=4"],
-    "fn_w8g3_p0": ["-DMVN_FN_WAVES=8", "-DMVN_FN_WGS=3", "-DMVN_FN_PRIO=0"], "fn_w8g3_p2": ["-DMVN_FN_WAVES=8", "-DMVN_FN_WGS=3", "-DMVN_FN_PRIO=2"],
-    "fn_w8g3_p3": ["-DMVN_FN_WAVES=8", "-DMVN_FN_WGS=3", "-DMVN_FN_PRIO=3"],
-    "fn_w8g3_p4": ["-DMVN_FN_WAVES=8", "-DMVN_FN_WGS=3", "-DMVN_FN_PRIO=4"], "fn_wg5_p4": ["-DMVN_FN_PRIO=4"],
-    "fn_wg5_p2": ["-DMVN_FN_PRIO=2"], "fn_wg5_p3": ["-DMVN_FN_PRIO=3"],
+    "fn_noprio": ["-DMVN_FN_PRIO=0"],
     "fn_w8g3": ["-DMVN_FN_WAVES=8", "-DMVN_FN_WGS=3"], "fn_w8g2": ["-DMVN_FN_WAVES=8", "-DMVN_FN_WGS=2"],
-    "fn_w16g1": ["-DMVN_FN_WAVES=16", "-DMVN_FN_WGS=1"], "fn_w2g10": ["-DMVN_FN_WAVES=2", "-DMVN_FN_WGS=10"],
 }
 for _k in DEFS:
     VARIANTS.setdefault(_k, [])

@@ -15,7 +15,7 @@ static const char* kSym = "_ZN12_GLOBAL__N_120vnet16_fusedn_kernelILb0ELi2EEEvPK
 
 struct Args {
     const float* y; long y_ld; const float *W1, *b1, *W2, *b2, *W3, *b3; float* dec; long dec_ld; float* logits; float* fm;
-    long B; int T; const float* tx; long tx_ld; int K; const unsigned char* mask; unsigned long long* counters; long final_blocks;
+    long B; int T; const float* tx; long tx_ld; int K; const unsigned char* mask; unsigned long long* counters;
 };
 
 static double run(const char* path, Args a, int reps, std::vector<float>* out) {
@@ -23,13 +23,13 @@ static double run(const char* path, Args a, int reps, std::vector<float>* out) {
     CHECK(hipModuleLoad(&mod, path));
     CHECK(hipModuleGetFunction(&fn, mod, kSym));
     void* params[] = {&a.y, &a.y_ld, &a.W1, &a.b1, &a.W2, &a.b2, &a.W3, &a.b3, &a.dec, &a.dec_ld, &a.logits, &a.fm,
-                      &a.B, &a.T, &a.tx, &a.tx_ld, &a.K, &a.mask, &a.counters, &a.final_blocks};
-    const unsigned grid = (unsigned)((a.B + 3) / 4);
+                      &a.B, &a.T, &a.tx, &a.tx_ld, &a.K, &a.mask, &a.counters};
+    const unsigned grid = (unsigned)((a.B + 7) / 8);
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     std::vector<double> ts;
     for (int r = 0; r < reps + 3; ++r) {
         CHECK(hipEventRecord(e0));
-        for (int k = 0; k < 5; ++k) CHECK(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, 0, params, nullptr));
+        for (int k = 0; k < 5; ++k) CHECK(hipModuleLaunchKernel(fn, grid, 1, 1, 512, 1, 1, 0, 0, params, nullptr));
         CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
         if (r >= 3) ts.push_back(ms / 5);
@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
     for (auto& v : W3) v = 0.14f * ud(rng); for (auto& v : b3) v = 0.14f * ud(rng);
     auto up = [](const std::vector<float>& h) { float* d; CHECK(hipMalloc(&d, h.size() * 4)); CHECK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice)); return d; };
     Args a{}; a.y = up(y); a.y_ld = T; a.W1 = up(W1); a.b1 = up(b1); a.W2 = up(W2); a.b2 = up(b2); a.W3 = up(W3); a.b3 = up(b3);
-    CHECK(hipMalloc(&a.dec, (size_t)B * T * 4)); CHECK(hipMemset(a.dec, 0, (size_t)B * T * 4)); a.dec_ld = T; a.B = B; a.T = T; a.final_blocks = 5120;
+    CHECK(hipMalloc(&a.dec, (size_t)B * T * 4)); CHECK(hipMemset(a.dec, 0, (size_t)B * T * 4)); a.dec_ld = T; a.B = B; a.T = T;
     std::vector<float> d0, d1;
     const double ms = run(argv[1], a, 9, &d0);
     printf("%-40s B=%ld  median %.4f ms  = %.1f cycles/symbol/SIMD @2.4GHz", argv[1], B, ms, ms * 1e-3 * 2.4e9 * 1024 / ((double)B * T));
