@@ -387,6 +387,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 
 #include "vnet16_fused.inc"
 #include "vnet16_fusedn.inc"
+#include "vnet16_coop.inc"
 #include "sweep16_rows.inc"
 #include "sweep16_lds.inc"
 #include "sweep16_quad.inc"
@@ -498,6 +499,14 @@ bool unfused_forced() {
     return e && e[0] == '1';
 }
 
+// Small batches take the cooperative kernel (vnet16_coop.inc); MVN_COOP=0|1 pins the choice (A/B runs, tests).
+bool coop_selected(int64_t B, int T) {
+    if (T > kCoopMaxT) return false;
+    const char *e = getenv("MVN_COOP");
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    return B <= kCoopMaxBlocks;
+}
+
 // MVN_FUSEDN=2|4 pins the tiles per super-tile of the fused kernel (vnet16_fusedn.inc); default 2 (5 waves/SIMD).
 int fusedn_tiles() {
     const char *e = getenv("MVN_FUSEDN");
@@ -529,6 +538,25 @@ int launch_vnet16_fused(const float *y, int64_t y_ld, const float *W1, const flo
                         const float *W3, const float *b3, float *dec, int64_t dec_ld, float *logits_out,
                         float *final_metric, int64_t B, int T, const float *tx, int64_t tx_ld, int K,
                         const unsigned char *row_mask, unsigned long long *counters, hipStream_t st) {
+    if (coop_selected(B, T)) {  // small batch: a 16-wave workgroup per block (MLP tiles in parallel, one sweeping wave)
+        const size_t dyn = (size_t)((T + 15) / 16) * 1024;
+        static size_t lds_allowed[2] = {0, 0};
+        const int slot = logits_out ? 1 : 0;
+        if (dyn > lds_allowed[slot]) {
+            const void *fn = logits_out ? (const void *)vnet16_coop_kernel<true> : (const void *)vnet16_coop_kernel<false>;
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kCoopMaxT / 16 * 1024));
+            if (e != hipSuccess) return (int)e;
+            lds_allowed[slot] = (size_t)(kCoopMaxT / 16 * 1024);
+        }
+        if (logits_out)
+            hipLaunchKernelGGL((vnet16_coop_kernel<true>), dim3((unsigned)B), dim3(64 * kCoopWaves), dyn, st, y, y_ld, W1, b1, W2, b2, W3,
+                               b3, dec, dec_ld, logits_out, final_metric, B, T, tx, tx_ld, K, row_mask, counters);
+        else
+            hipLaunchKernelGGL((vnet16_coop_kernel<false>), dim3((unsigned)B), dim3(64 * kCoopWaves), dyn, st, y, y_ld, W1, b1, W2, b2, W3,
+                               b3, dec, dec_ld, logits_out, final_metric, B, T, tx, tx_ld, K, row_mask, counters);
+        if (tx) hipLaunchKernelGGL(count_totals_kernel, dim3(1), dim3(1024), 0, st, row_mask, B, K, counters);
+        return (int)hipGetLastError();
+    }
     const int nt = fusedn_tiles();  // NT = 2 runs 5 waves/SIMD (default); NT = 4 is the 64-symbol form, kept as a cross-check
     const unsigned gridn = (unsigned)((B + kFusedNWaves - 1) / kFusedNWaves);
 #define MVN_FUSEDN_LAUNCH(WL, NT)                                                                                      \
@@ -717,11 +745,13 @@ int mvn_va_decode_kernel_name(int64_t B, int32_t T, int32_t S, char *name, int32
 }
 
 int mvn_vnet_decode_kernel_name(int64_t B, int32_t T, int32_t S, int32_t want_logits, char *name, int32_t name_len) {
-    (void)T;
     if (!valid_states(S)) return MVN_E_STATES;
     if (!name || name_len < 1) return MVN_E_NULL;
     if (S == 16 && !unfused_forced()) {
-        snprintf(name, (size_t)name_len, "vnet16_fusedn_kernel<%s, %d>", want_logits ? "true" : "false", fusedn_tiles());
+        if (coop_selected(B, T))
+            snprintf(name, (size_t)name_len, "vnet16_coop_kernel<%s>", want_logits ? "true" : "false");
+        else
+            snprintf(name, (size_t)name_len, "vnet16_fusedn_kernel<%s, %d>", want_logits ? "true" : "false", fusedn_tiles());
     } else {  // two launches: the MLP, then the sweep over its logits (scratch or logits_out: 16-byte aligned, row stride T)
         char sw[64];
         sweep_kernel_name<MODE_NEGLOGIT>(plan_sweep<MODE_NEGLOGIT>(nullptr, nullptr, 0, B, S), S, nullptr, 0, sw, sizeof sw);

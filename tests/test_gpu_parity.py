@@ -231,9 +231,10 @@ def test_vnet16_fused_and_unfused_paths(oracle, dev, monkeypatch, B, T):
     rdec, rlg, rfm = oracle.vnet_decode(y, w, want_logits=True, want_final=True)
     lib = mvn._lib.load()
     ws = torch.empty(B * T * S * 4, dtype=torch.uint8, device=dev)
-    for unfused, nt in (("0", "2"), ("0", "4"), ("1", "2")):
+    for unfused, nt, coop in (("0", "2", "0"), ("0", "4", "0"), ("0", "2", "1"), ("1", "2", "0")):
         monkeypatch.setenv("MVN_UNFUSED", unfused)
-        monkeypatch.setenv("MVN_FUSEDN", nt)  # 32-symbol (5 waves/SIMD, default) or 64-symbol super-tiles of the fused kernel
+        monkeypatch.setenv("MVN_FUSEDN", nt)  # 32-symbol (6 waves/SIMD, default) or 64-symbol super-tiles of the fused kernel
+        monkeypatch.setenv("MVN_COOP", coop)  # one wave per block / a 16-wave workgroup per block (the small-batch kernel)
         for want_logits in (False, True):
             dec = torch.zeros_like(yt)
             fm = torch.empty(B, S, device=dev)
@@ -298,6 +299,8 @@ def test_sweep16_quad_variant(oracle, dev, monkeypatch):
     assert (lib.mvn_va_decode_kernel_name(100, 1000, 16, buf, 64), buf.value) == (0, b"sweep16_rows_kernel<2>")
     assert (lib.mvn_va_decode_kernel_name(10000, 1000, 16, buf, 64), buf.value) == (0, b"va16_quad_kernel")
     assert (lib.mvn_vnet_decode_kernel_name(10000, 1000, 16, 0, buf, 64), buf.value) == (0, b"vnet16_fusedn_kernel<false, 2>")
+    assert (lib.mvn_vnet_decode_kernel_name(1, 136, 16, 0, buf, 64), buf.value) == (0, b"vnet16_coop_kernel<false>")
+    assert (lib.mvn_vnet_decode_kernel_name(1, 2000, 16, 1, buf, 64), buf.value) == (0, b"vnet16_fusedn_kernel<true, 2>")  # T > 1024
     assert (lib.mvn_vnet_decode_kernel_name(10, 100, 64, 0, buf, 64), buf.value) == (0, b"mlp_kernel<4> + sweep_inplace_kernel<4, 1, 4>")
     rng = np.random.RandomState(77)
     cost = rng.normal(0, 2, (B, T, S)).astype(np.float32)

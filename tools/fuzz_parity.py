@@ -19,7 +19,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device("cuda:0")
 lib, st, ptr = mvn._lib.load(), mvn._lib.current_stream(dev), mvn._lib.ptr
-ENV = ["MVN_SWEEP16", "MVN_VA16", "MVN_VA_INPLACE", "MVN_SWEEP_INPLACE", "MVN_GENERIC_SWEEP", "MVN_UNFUSED", "MVN_FUSEDN"]
+ENV = ["MVN_SWEEP16", "MVN_VA16", "MVN_VA_INPLACE", "MVN_SWEEP_INPLACE", "MVN_GENERIC_SWEEP", "MVN_UNFUSED", "MVN_FUSEDN", "MVN_COOP"]
 
 
 def strided(a, pad):
@@ -47,6 +47,8 @@ while time.time() < t_end:
         os.environ["MVN_SWEEP16"] = str(rng.choice(["rows", "lds", "quad"]))
         os.environ["MVN_VA16"] = str(rng.choice(["rows", "quad"]))
         os.environ["MVN_FUSEDN"] = str(rng.choice(["2", "4"]))
+        if rng.rand() < 0.5:
+            os.environ["MVN_COOP"] = str(rng.choice(["0", "1"]))
     if rng.rand() < 0.3:
         os.environ["MVN_VA_INPLACE"] = "1"
     if rng.rand() < 0.3:
