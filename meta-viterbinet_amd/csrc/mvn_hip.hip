@@ -388,6 +388,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 #include "vnet16_fused.inc"
 #include "vnet16_fusedn.inc"
 #include "vnet16_coop.inc"
+#include "va16_tile.inc"
 #include "sweep16_rows.inc"
 #include "sweep16_lds.inc"
 #include "sweep16_quad.inc"
@@ -583,7 +584,7 @@ bool generic_sweep_forced() { return env_is("MVN_GENERIC_SWEEP", '1'); }
 
 // Which kernel serves a sweep: ONE decision function used by the dispatcher and by the mvn_*_kernel_name queries, so the
 // name a caller is told is the kernel that runs (same environment switches, same alignment fall-backs).
-enum SweepKind { SK_GENERIC, SK_VA_INPLACE, SK_SWEEP_INPLACE, SK_S16_QUAD, SK_S16_LDS, SK_S16_ROWS, SK_VA16_QUAD };
+enum SweepKind { SK_GENERIC, SK_VA_INPLACE, SK_SWEEP_INPLACE, SK_S16_QUAD, SK_S16_LDS, SK_S16_ROWS, SK_VA16_QUAD, SK_VA16_TILE };
 
 template <int MODE>
 SweepKind plan_sweep(const void *src, const void *dec, int64_t dec_ld, int64_t B, int S) {
@@ -592,9 +593,10 @@ SweepKind plan_sweep(const void *src, const void *dec, int64_t dec_ld, int64_t B
         // classical VA: the lane-bits x register-bits in-place kernel serves every S >= 4 except S = 16, which has its
         // own 16-blocks-per-wave / row kernels (MVN_VA_INPLACE=1 sends S = 16 there too, for cross-checks)
         if (S >= 4 && !generic && (S != 16 || env_is("MVN_VA_INPLACE", '1'))) return SK_VA_INPLACE;
-        if (S == 16 && !generic) {  // MVN_VA16 = "rows" | "quad" pins a variant (A/B, tests); default by size
-            const char *e = getenv("MVN_VA16");
-            return (e ? e[0] == 'q' : B >= kVaQuadMinBlocks) ? SK_VA16_QUAD : SK_S16_ROWS;
+        if (S == 16 && !generic) {  // MVN_VA16 = "rows" | "quad" | "tile" pins a variant (A/B, tests); default by size:
+            const char *e = getenv("MVN_VA16");  // one wave per block below 6 000 blocks, 16 blocks per wave from there on
+            if (e && (e[0] == 'r' || e[0] == 'q' || e[0] == 't')) return e[0] == 'q' ? SK_VA16_QUAD : e[0] == 't' ? SK_VA16_TILE : SK_S16_ROWS;
+            return B >= kVaQuadMinBlocks ? SK_VA16_QUAD : SK_VA16_TILE;
         }
         return SK_GENERIC;
     } else {
@@ -631,6 +633,7 @@ void sweep_kernel_name(SweepKind k, int S, const void *dec, int64_t dec_ld, char
         case SK_S16_LDS: snprintf(name, n, "sweep16_lds_kernel<%d>", MODE); break;
         case SK_S16_ROWS: snprintf(name, n, "sweep16_rows_kernel<%d>", MODE); break;
         case SK_VA16_QUAD: snprintf(name, n, "va16_quad_kernel"); break;
+        case SK_VA16_TILE: snprintf(name, n, "va16_tile_kernel"); break;
         default: snprintf(name, n, "sweep_kernel<%d, %d>", S, MODE); break;
     }
 }
@@ -644,6 +647,9 @@ int dispatch_sweep(const float *src, int64_t src_ld, const float *priors, int64_
             break;
         case SK_VA16_QUAD:
             if constexpr (MODE == MODE_VA) return launch_va16_quad(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
+            break;
+        case SK_VA16_TILE:
+            if constexpr (MODE == MODE_VA) return launch_va16_tile(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
             break;
         case SK_SWEEP_INPLACE:
             if constexpr (MODE != MODE_VA) return launch_sweep_inplace<MODE>(src, dec, dec_ld, final_metric, B, T, S, st);

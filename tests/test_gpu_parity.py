@@ -262,10 +262,10 @@ def test_sweep16_rows_and_generic_paths(oracle, dev, monkeypatch, B, T):
     rdec, rfm = oracle.acs_sweep(cost)
     vdec, vfm = oracle.va_decode(y, pri)
     ct, yt, pt = torch.tensor(cost, device=dev), torch.tensor(y, device=dev), torch.tensor(pri, device=dev)
-    for generic, variant in (("0", "lds"), ("0", "rows"), ("0", "quad"), ("1", "lds")):
+    for generic, variant, va in (("0", "lds", "tile"), ("0", "rows", "rows"), ("0", "quad", "quad"), ("1", "lds", "rows")):
         monkeypatch.setenv("MVN_GENERIC_SWEEP", generic)
         monkeypatch.setenv("MVN_SWEEP16", variant)  # LDS-DMA streaming vs register-prefetch row sweep
-        monkeypatch.setenv("MVN_VA16", "quad" if variant == "quad" else "rows")  # 16 / 4 blocks per wave
+        monkeypatch.setenv("MVN_VA16", va)  # one block per wave (default below 6 000 blocks) / 4 / 16 blocks per wave
         dec, fm = mvn.acs_sweep(ct, return_final=True)
         assert np.array_equal(_np(dec), rdec) and np.array_equal(_np(fm), rfm), generic
         d2 = torch.zeros_like(yt)
@@ -296,7 +296,7 @@ def test_sweep16_quad_variant(oracle, dev, monkeypatch):
     assert name(None, None, 52, B, T, S) == (0, "sweep16_rows_kernel<0>")
     monkeypatch.delenv("MVN_SWEEP16")
     assert (lib.mvn_va_decode_kernel_name(125000, 1000, 256, buf, 64), buf.value) == (0, b"va_inplace_kernel<6>")
-    assert (lib.mvn_va_decode_kernel_name(100, 1000, 16, buf, 64), buf.value) == (0, b"sweep16_rows_kernel<2>")
+    assert (lib.mvn_va_decode_kernel_name(100, 1000, 16, buf, 64), buf.value) == (0, b"va16_tile_kernel")
     assert (lib.mvn_va_decode_kernel_name(10000, 1000, 16, buf, 64), buf.value) == (0, b"va16_quad_kernel")
     assert (lib.mvn_vnet_decode_kernel_name(10000, 1000, 16, 0, buf, 64), buf.value) == (0, b"vnet16_fusedn_kernel<false, 2>")
     assert (lib.mvn_vnet_decode_kernel_name(1, 136, 16, 0, buf, 64), buf.value) == (0, b"vnet16_coop_kernel<false>")
@@ -944,7 +944,7 @@ def test_nonfinite_samples_like_reference(oracle, dev, monkeypatch):
     assert np.array_equal(_np(det(yt, "val")), rdec)
     assert np.all(rdec[1, 22:] == 0) and np.all(rdec[2, 2:] == 0)  # everything after a NaN sample decodes to 0
     pt = torch.tensor(pri, device=dev)
-    for variant in ("rows", "quad"):
+    for variant in ("rows", "quad", "tile"):
         monkeypatch.setenv("MVN_VA16", variant)
         d2 = torch.zeros_like(yt)
         rc = mvn._lib.load().mvn_va_decode_f32(mvn._lib.ptr(yt), T, mvn._lib.ptr(pt), 1, mvn._lib.ptr(d2), T, None, B, T, S,
