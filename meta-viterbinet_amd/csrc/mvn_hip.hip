@@ -67,12 +67,12 @@ __device__ __forceinline__ float sigmoid_from_neg(float d) {
     return 1.0f / (1.0f + e);  // IEEE division (hipcc default: correctly rounded)
 }
 
-// va_detector.py:64-68, four separately rounded ops.
+// va_detector.py:64-68, four separately rounded ops (three instructions: see below).
 __device__ __forceinline__ float va_cost(float y, float prior) {
     float d = y - prior;
     float sq = d * d;
-    float half = sq * 0.5f;
-    return half - 0.91893853320467274178f;
+    // sq * 0.5f is exact (or underflows far below half an ulp of the constant), so one fma rounds like the two ops
+    return __builtin_fmaf(sq, 0.5f, -0.91893853320467274178f);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -394,6 +394,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 #include "sweep16_quad.inc"
 #include "va16_quad.inc"
 #include "va_inplace.inc"
+#include "va256_wave.inc"
 #include "sweep_inplace.inc"
 #include "rs_codec.inc"
 #include "online_train.inc"
@@ -584,7 +585,7 @@ bool generic_sweep_forced() { return env_is("MVN_GENERIC_SWEEP", '1'); }
 
 // Which kernel serves a sweep: ONE decision function used by the dispatcher and by the mvn_*_kernel_name queries, so the
 // name a caller is told is the kernel that runs (same environment switches, same alignment fall-backs).
-enum SweepKind { SK_GENERIC, SK_VA_INPLACE, SK_SWEEP_INPLACE, SK_S16_QUAD, SK_S16_LDS, SK_S16_ROWS, SK_VA16_QUAD, SK_VA16_TILE };
+enum SweepKind { SK_GENERIC, SK_VA256_WAVE, SK_VA_INPLACE, SK_SWEEP_INPLACE, SK_S16_QUAD, SK_S16_LDS, SK_S16_ROWS, SK_VA16_QUAD, SK_VA16_TILE };
 
 template <int MODE>
 SweepKind plan_sweep(const void *src, const void *dec, int64_t dec_ld, int64_t B, int S) {
@@ -592,6 +593,8 @@ SweepKind plan_sweep(const void *src, const void *dec, int64_t dec_ld, int64_t B
     if constexpr (MODE == MODE_VA) {
         // classical VA: the lane-bits x register-bits in-place kernel serves every S >= 4 except S = 16, which has its
         // own 16-blocks-per-wave / row kernels (MVN_VA_INPLACE=1 sends S = 16 there too, for cross-checks)
+        // (and S = 256, one block per wave with scalar decisions; MVN_VA256=inplace keeps the family kernel there)
+        if (S == 256 && !generic && !env_is("MVN_VA256", 'i')) return SK_VA256_WAVE;
         if (S >= 4 && !generic && (S != 16 || env_is("MVN_VA_INPLACE", '1'))) return SK_VA_INPLACE;
         if (S == 16 && !generic) {  // MVN_VA16 = "rows" | "quad" | "tile" pins a variant (A/B, tests); default by size:
             const char *e = getenv("MVN_VA16");  // one wave per block below 6 000 blocks, 16 blocks per wave from there on
@@ -624,6 +627,7 @@ template <int MODE>
 void sweep_kernel_name(SweepKind k, int S, const void *dec, int64_t dec_ld, char *name, size_t n) {
     const int lb = log2_states(S) - 2;
     switch (k) {
+        case SK_VA256_WAVE: snprintf(name, n, "va256_wave_kernel"); break;
         case SK_VA_INPLACE: snprintf(name, n, "va_inplace_kernel<%d>", lb); break;
         case SK_SWEEP_INPLACE: snprintf(name, n, "sweep_inplace_kernel<%d, %d, %d>", lb, MODE, lb >= 2 ? 4 : lb == 1 ? 8 : 16); break;
         case SK_S16_QUAD:
@@ -642,6 +646,9 @@ template <int MODE>
 int dispatch_sweep(const float *src, int64_t src_ld, const float *priors, int64_t Bp, float *dec, int64_t dec_ld,
                    float *final_metric, int64_t B, int T, int S, hipStream_t st) {
     switch (plan_sweep<MODE>(src, dec, dec_ld, B, S)) {
+        case SK_VA256_WAVE:
+            if constexpr (MODE == MODE_VA) return launch_va256_wave(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
+            break;
         case SK_VA_INPLACE:
             if constexpr (MODE == MODE_VA) return launch_va_inplace(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, S, st);
             break;

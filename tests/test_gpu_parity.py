@@ -295,7 +295,7 @@ def test_sweep16_quad_variant(oracle, dev, monkeypatch):
     monkeypatch.setenv("MVN_SWEEP16", "rows")
     assert name(None, None, 52, B, T, S) == (0, "sweep16_rows_kernel<0>")
     monkeypatch.delenv("MVN_SWEEP16")
-    assert (lib.mvn_va_decode_kernel_name(125000, 1000, 256, buf, 64), buf.value) == (0, b"va_inplace_kernel<6>")
+    assert (lib.mvn_va_decode_kernel_name(125000, 1000, 256, buf, 64), buf.value) == (0, b"va256_wave_kernel")
     assert (lib.mvn_va_decode_kernel_name(100, 1000, 16, buf, 64), buf.value) == (0, b"va16_tile_kernel")
     assert (lib.mvn_va_decode_kernel_name(10000, 1000, 16, buf, 64), buf.value) == (0, b"va16_quad_kernel")
     assert (lib.mvn_vnet_decode_kernel_name(10000, 1000, 16, 0, buf, 64), buf.value) == (0, b"vnet16_fusedn_kernel<false, 2>")
@@ -699,6 +699,41 @@ def test_eval_by_word_self_supervised_tracks_channel(golden, dev):
     assert ser_online[100:].mean() <= ser_frozen[100:].mean() + 2e-3
 
 
+@pytest.mark.parametrize("B,T,Bp", [(1, 1, 1), (3, 7, 1), (2, 8, 2), (5, 63, 1), (4, 64, 4), (6, 65, 3), (9, 129, 1), (7, 1000, 1)])
+def test_va256_wave_and_family_kernels(oracle, dev, monkeypatch, B, T, Bp):
+    """S = 256: the one-block-per-wave kernel with scalar decisions (default) and the lane-bits x register-bits family
+    kernel (MVN_VA256=inplace) against the oracle, on inputs built to hit the tie path: samples and priors on a coarse
+    dyadic grid (path metrics of different states coincide exactly long after the first 8 steps), an all-zero row
+    (every step ties), NaN / inf samples, a row stride above T, several prior rows."""
+    S = 256
+    rng = np.random.RandomState(B * 977 + T)
+    y = (np.round(rng.normal(0, 1.5, (B, T + 5)) * 2) / 2).astype(np.float32)
+    if B > 1:
+        y[1] = 0.0
+    if B > 2:
+        y[2] = rng.normal(0, 1.5, T + 5).astype(np.float32)  # one ordinary row
+        y[2, T // 2] = np.nan
+    if B > 3:
+        y[3, T // 3] = np.inf
+    pri = (np.round(rng.normal(0, 1, (Bp, S)) * 4) / 4).astype(np.float32)
+    pri[0] = np.concatenate([np.linspace(-2, 2, S // 2), -np.linspace(-2, 2, S // 2)]).astype(np.float32)
+    with np.errstate(all="ignore"):
+        rdec, rfm = oracle.va_decode(y, pri, T=T)
+    yt, pt = torch.tensor(y, device=dev), torch.tensor(pri, device=dev)
+    lib, st = mvn._lib.load(), mvn._lib.current_stream(dev)
+    buf = ctypes.create_string_buffer(64)
+    for variant, name in (("", b"va256_wave_kernel"), ("inplace", b"va_inplace_kernel<6>")):
+        monkeypatch.setenv("MVN_VA256", variant)
+        assert (lib.mvn_va_decode_kernel_name(B, T, S, buf, 64), buf.value) == (0, name)
+        dec = torch.full_like(yt, 7.0)
+        fm = torch.empty(B, S, device=dev)
+        assert lib.mvn_va_decode_f32(mvn._lib.ptr(yt), T + 5, mvn._lib.ptr(pt), Bp, mvn._lib.ptr(dec), T + 5, mvn._lib.ptr(fm), B, T,
+                                     S, st) == 0
+        assert np.array_equal(_np(dec[:, :T]), rdec[:, :T]), variant
+        assert np.array_equal(_np(fm), rfm, equal_nan=True), variant
+        assert bool((dec[:, T:] == 7.0).all())
+
+
 @pytest.mark.parametrize("L", [2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("B,T", [(1, 1), (2, 7), (3, 8), (5, 63), (4, 64), (70, 65), (33, 200), (9, 1000)])
 def test_va_inplace_and_generic_paths(oracle, dev, monkeypatch, L, B, T):
@@ -1044,7 +1079,7 @@ def _by_word_words(dev, coefficients, snr, seed, N=300, K=120, nsym=2, L=4):
 @pytest.mark.timeout(300)
 def test_config3_va_l8_full_per_gpu_share(oracle, dev):
     """BASELINE configs[3] at one GPU's share: classical VA, L = 8 (256 states), 125 000 blocks x 1000 symbols through
-    mvn_va_decode_f32 (va_inplace_kernel<6>).  A strided 256-block sample is compared with the oracle bit for bit
+    mvn_va_decode_f32 (va256_wave_kernel).  A strided 256-block sample is compared with the oracle bit for bit
     (decisions and final path metrics); block independence at full size: a permutation of the blocks permutes the
     decisions, and a re-decoded contiguous slice equals the slice of the full decode."""
     L, S, B, T = 8, 256, 125000, 1000

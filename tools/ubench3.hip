@@ -23,11 +23,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define REP16(x) REP8(x) REP8(x)
 
 enum Role { IDLE = 0, R_MFMA, R_SIGMOID, R_FMAC, R_INT, R_RCP, R_MOV, R_DPP, R_PERMSWAP, R_FMA3, R_FMAAK, R_MULLIT, R_LSHLADD,
-            R_FMACLIT, R_LDSREAD, R_SIGMOID2, R_MFMA4x4, R_K0, R_K1, R_K2, R_MFMA_DIFF, R_K3, R_K4, N_ROLES };
+            R_FMACLIT, R_LDSREAD, R_SIGMOID2, R_MFMA4x4, R_K0, R_K1, R_K2, R_MFMA_DIFF, R_K3, R_K4, R_PKMUL, R_PKADD, R_VCMP, R_VCMPS, R_SALU, R_MIN3, R_CNDMASK, N_ROLES };
 static const char* kRoleName[N_ROLES] = {"-", "M", "Vsig", "Vfmac", "Vint", "Vrcp", "Vmov", "Vdpp", "Vswap", "Vfma3", "Vfmaak",
-                                         "Vmullit", "Vlshladd", "Vfmaclit", "Vlds", "Vsig2", "M4x4", "K0", "K1", "K2", "Mdiff", "K3bar", "K4bar2"};
+                                         "Vmullit", "Vlshladd", "Vfmaclit", "Vlds", "Vsig2", "M4x4", "K0", "K1", "K2", "Mdiff", "K3bar", "K4bar2", "Vpkmul", "Vpkadd", "Vcmp", "VcmpS", "Salu", "Vmin3", "Vcndmask"};
 // wave-instructions per loop iteration of each role (for cycles/instruction)
-static const int kOpsPerIter[N_ROLES] = {0, 16, 80, 64, 64, 32, 64, 64, 32, 64, 64, 64, 64, 64, 32, 160, 32, 92, 92, 92, 16, 92, 184};
+static const int kOpsPerIter[N_ROLES] = {0, 16, 80, 64, 64, 32, 64, 64, 32, 64, 64, 64, 64, 64, 32, 160, 32, 92, 92, 92, 16, 92, 184, 64, 64, 64, 64, 64, 64, 64};
 
 #define SIG1(D, Y)                                                                                                     \
     "v_fma_f32 %[t0], " Y ", %[a], %[b]\n v_mul_f32 %[t1], 0x3fb8aa3b, %[t0]\n v_add_f32 %[t1], 0x4b400000, %[t1]\n"      \
@@ -235,6 +235,58 @@ __global__ __launch_bounds__(1024) void kroles(Stamp* out, float* sink, const in
                               "v_fmac_f32 %4, 0xbf317200, %8\n v_fmac_f32 %5, 0xb5bfbe8e, %8\n v_fmac_f32 %6, 0xbf317200, %8\n v_fmac_f32 %7, 0xb5bfbe8e, %8\n"
                               : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));)
         }
+    } else if (role == R_PKMUL || role == R_PKADD) {  // packed f32: two lanes of arithmetic per instruction
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 p0 = {x0, x1}, p1 = {x1, x2}, p2 = {x2, x3}, p3 = {x3, x4}, p4 = {x4, x5}, p5 = {x5, x6}, p6 = {x6, x7}, p7 = {x7, x0};
+        const f32x2 pa = {a, b};
+        for (int it = 0; it < n; ++it) {
+            if (role == R_PKMUL) {
+                REP8(asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n"
+                                  "v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8\n"
+                                  : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pa));)
+            } else {
+                REP8(asm volatile("v_pk_add_f32 %0, %0, %8 op_sel_hi:[1,0]\n v_pk_add_f32 %1, %1, %8 op_sel_hi:[1,0]\n v_pk_add_f32 %2, %2, %8 op_sel_hi:[1,0]\n v_pk_add_f32 %3, %3, %8 op_sel_hi:[1,0]\n"
+                                  "v_pk_add_f32 %4, %4, %8 op_sel_hi:[1,0]\n v_pk_add_f32 %5, %5, %8 op_sel_hi:[1,0]\n v_pk_add_f32 %6, %6, %8 op_sel_hi:[1,0]\n v_pk_add_f32 %7, %7, %8 op_sel_hi:[1,0]\n"
+                                  : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pa));)
+            }
+        }
+        x0 = p0[0] + p1[1] + p2[0] + p3[1] + p4[0] + p5[1] + p6[0] + p7[1];
+    } else if (role == R_VCMP) {  // VOPC into vcc
+        for (int it = 0; it < n; ++it) {
+            REP8(asm volatile("v_cmp_eq_f32 vcc, %0, %1\n v_cmp_eq_f32 vcc, %1, %2\n v_cmp_eq_f32 vcc, %2, %3\n v_cmp_eq_f32 vcc, %3, %4\n"
+                              "v_cmp_eq_f32 vcc, %4, %5\n v_cmp_eq_f32 vcc, %5, %6\n v_cmp_eq_f32 vcc, %6, %7\n v_cmp_eq_f32 vcc, %7, %0\n"
+                              :: "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7) : "vcc");)
+        }
+    } else if (role == R_VCMPS) {  // VOP3 compare into an SGPR pair, each followed by the scalar use of the mask
+        unsigned long long acc = 0;
+        for (int it = 0; it < n; ++it) {
+            REP8(asm volatile("v_cmp_eq_f32 s[40:41], %1, %2\n v_cmp_eq_f32 s[42:43], %2, %3\n v_cmp_eq_f32 s[44:45], %3, %4\n v_cmp_eq_f32 s[46:47], %4, %5\n"
+                              "v_cmp_eq_f32 s[48:49], %5, %6\n v_cmp_eq_f32 s[50:51], %6, %7\n v_cmp_eq_f32 s[52:53], %7, %8\n v_cmp_eq_f32 s[54:55], %8, %1\n"
+                              "s_or_b64 %0, %0, s[40:41]\n s_or_b64 %0, %0, s[54:55]\n"
+                              : "+s"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7)
+                              : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55");)
+        }
+        x0 += (float)(acc & 1);
+    } else if (role == R_SALU) {  // dependent and independent scalar work, no VALU at all
+        unsigned long long s0 = hwid, s1 = hwid + 1, s2 = hwid + 2, s3 = hwid + 3;
+        for (int it = 0; it < n; ++it) {
+            REP8(asm volatile("s_and_b64 %0, %0, %1\n s_or_b64 %1, %1, %2\n s_xor_b64 %2, %2, %3\n s_andn2_b64 %3, %3, %0\n"
+                              "s_and_b64 %0, %0, %2\n s_or_b64 %1, %1, %3\n s_xor_b64 %2, %2, %0\n s_andn2_b64 %3, %3, %1\n"
+                              : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3));)
+        }
+        x0 += (float)((s0 ^ s1 ^ s2 ^ s3) & 1);
+    } else if (role == R_MIN3) {
+        for (int it = 0; it < n; ++it) {
+            REP8(asm volatile("v_min3_f32 %0, %0, %8, %9\n v_min3_f32 %1, %1, %8, %9\n v_min3_f32 %2, %2, %8, %9\n v_min3_f32 %3, %3, %8, %9\n"
+                              "v_min3_f32 %4, %4, %8, %9\n v_min3_f32 %5, %5, %8, %9\n v_min3_f32 %6, %6, %8, %9\n v_min3_f32 %7, %7, %8, %9\n"
+                              : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));)
+        }
+    } else if (role == R_CNDMASK) {
+        for (int it = 0; it < n; ++it) {
+            REP8(asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                              "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                              : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a) : "vcc");)
+        }
     } else if (role == R_LDSREAD) {  // ds_read_b128 stream (the kernel's weight fetches)
         const unsigned addr = (unsigned)(size_t)(&ldsbuf[0]) + (lane & 15) * 16;
         f32x4 v0, v1, v2, v3;
@@ -320,6 +372,28 @@ int main(int argc, char** argv) {
     iters[R_MFMA] = mf; iters[R_MFMA4x4] = 8000; iters[R_SIGMOID] = 5000; iters[R_SIGMOID2] = 2500; iters[R_RCP] = 8000;
     iters[R_PERMSWAP] = 8000; iters[R_LDSREAD] = 4000;
 
+    if (argc > 1 && !strcmp(argv[1], "va")) {
+        printf("# part 4: instruction forms of the 256-state Viterbi kernel; Salu beside VALU roles on the same SIMD\n");
+        for (int role : {R_SALU, R_MIN3, R_CNDMASK, R_VCMP, R_FMAC, R_PKMUL, R_DPP}) {  // R_VCMPS did not finish in 300 s on the box: not run
+            for (int nw : {2, 4}) {
+                int roles[4] = {IDLE, IDLE, IDLE, IDLE};
+                for (int k = 0; k < nw; ++k) roles[k] = role;
+                Result r = run(roles, iters, 5);
+                const double ops = (double)iters[role] * kOpsPerIter[role] * nw;
+                printf("%-9s waves/SIMD=%d  span=%9.0f cyc  cyc/instr/SIMD=%6.2f  (%.2f GHz)%s\n", kRoleName[role], nw, r.span_cyc,
+                       r.span_cyc / ops, r.ghz, r.placement_ok ? "" : " (!! placement)");
+                fflush(stdout);
+            }
+        }
+        for (int v : {R_FMAC, R_DPP}) {
+            int v2[4] = {IDLE, IDLE, v, v}, sv[4] = {R_SALU, R_SALU, v, v}, s2[4] = {R_SALU, R_SALU, IDLE, IDLE};
+            char tag[64];
+            show("Salu alone (2 waves)", s2, iters);
+            snprintf(tag, sizeof tag, "%s alone (2 waves)", kRoleName[v]); show(tag, v2, iters);
+            snprintf(tag, sizeof tag, "2 x Salu beside 2 x %s", kRoleName[v]); show(tag, sv, iters);
+        }
+        return 0;
+    }
     if (argc <= 1 || strcmp(argv[1], "k"))
     printf("# part 1: issue cost per instruction form (one role on 1, 2, 4 waves of every SIMD; cycles per wave-instruction per SIMD)\n");
     for (int role = R_MFMA; role < R_K0 && (argc <= 1 || strcmp(argv[1], "k")); ++role) {
