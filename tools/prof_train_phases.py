@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Phase timeline of one iteration of the one-launch online-training kernel (diagnostic build -DMVN_DIAG_TRAIN: s_memtime at
+the barriers of iteration 100, returned through the loss buffer).  Build the diagnostic library first (no GPU needed):
+    python tools/prof_train_phases.py --build
+then on the GPU box:
+    python tools/prof_train_phases.py"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIAG_SO = os.path.join(ROOT, "tools", "libmvn_diag_train.so")
+if "--build" in sys.argv:
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + g.HIPCC_FLAGS + ["-DMVN_DIAG_TRAIN", g.HIP_SRC, "-o", DIAG_SO], check=True)
+    print("built", DIAG_SO)
+    sys.exit(0)
+
+os.environ["MVN_LIB_PATH"] = DIAG_SO
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+sys.path.insert(0, ROOT)
+import meta_viterbinet_amd as mvn  # noqa: E402
+
+dev = torch.device("cuda:0")
+T, L, S, N = 136, 4, 16, 200
+names = ["h1 = sigmoid(W1 y + b1)", "z2 = h1 W2^T (MFMA)", "logits = relu(z2) W3^T (MFMA)", "softmax / CE / dlogits",
+         "dz2, dW3, db3", "dz1 (MFMA), dW2 (MFMA), db2", "dW1, db1"]
+for full in (False, True):
+    torch.manual_seed(0)
+    tx = torch.randint(0, 2, (1, T)).float().to(dev)
+    rx = torch.randn(1, T).to(dev)
+    det = mvn.VNETDetector(S, {"train": T, "val": T}).to(dev)
+    tr = mvn.OnlineTrainer(det, L)
+    for _ in range(3):
+        loss = tr.online_training(tx, rx, iterations=N, full_word=full, return_loss=True)
+    torch.cuda.synchronize()
+    st = loss[102:122].cpu().numpy().view(np.uint64).astype(np.int64)
+    # stamps 0..7: the LAST chunk of iteration 100 (grad_chunk start, then after each barrier); 8: iteration start; 9: after Adam
+    it_total = st[9] - st[8]
+    print(f"--- {'full word (136 samples = 5 chunks)' if full else 'minibatch (32 samples = 1 chunk)'}: iteration 100 = {it_total} cycles of s_memtime (100 MHz counter x24 = 2.4 GHz?)")
+    for k in range(7):
+        print(f"  {names[k]:36s} {st[k+1]-st[k]:7d}")
+    print(f"  {'chunk total':36s} {st[7]-st[0]:7d}")
+    print(f"  {'Adam + loss + barrier':36s} {st[9]-st[7]:7d}")
+    print(f"  {'iteration start -> last chunk start':36s} {st[0]-st[8]:7d}")
