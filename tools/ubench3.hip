@@ -23,11 +23,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define REP16(x) REP8(x) REP8(x)
 
 enum Role { IDLE = 0, R_MFMA, R_SIGMOID, R_FMAC, R_INT, R_RCP, R_MOV, R_DPP, R_PERMSWAP, R_FMA3, R_FMAAK, R_MULLIT, R_LSHLADD,
-            R_FMACLIT, R_LDSREAD, R_SIGMOID2, R_MFMA4x4, R_K0, R_K1, R_K2, R_MFMA_DIFF, R_K3, R_K4, R_PKMUL, R_PKADD, R_VCMP, R_VCMPS, R_SALU, R_MIN3, R_CNDMASK, N_ROLES };
+            R_FMACLIT, R_LDSREAD, R_SIGMOID2, R_MFMA4x4, R_K0, R_K1, R_K2, R_MFMA_DIFF, R_K3, R_K4, R_PKMUL, R_PKADD, R_VCMP, R_VCMPS, R_SALU, R_MIN3, R_CNDMASK, R_MFMA2, R_MFMA1, N_ROLES };
 static const char* kRoleName[N_ROLES] = {"-", "M", "Vsig", "Vfmac", "Vint", "Vrcp", "Vmov", "Vdpp", "Vswap", "Vfma3", "Vfmaak",
-                                         "Vmullit", "Vlshladd", "Vfmaclit", "Vlds", "Vsig2", "M4x4", "K0", "K1", "K2", "Mdiff", "K3bar", "K4bar2", "Vpkmul", "Vpkadd", "Vcmp", "VcmpS", "Salu", "Vmin3", "Vcndmask"};
+                                         "Vmullit", "Vlshladd", "Vfmaclit", "Vlds", "Vsig2", "M4x4", "K0", "K1", "K2", "Mdiff", "K3bar", "K4bar2", "Vpkmul", "Vpkadd", "Vcmp", "VcmpS", "Salu", "Vmin3", "Vcndmask", "M2acc", "M1acc"};
 // wave-instructions per loop iteration of each role (for cycles/instruction)
-static const int kOpsPerIter[N_ROLES] = {0, 16, 80, 64, 64, 32, 64, 64, 32, 64, 64, 64, 64, 64, 32, 160, 32, 92, 92, 92, 16, 92, 184, 64, 64, 64, 64, 64, 64, 64};
+static const int kOpsPerIter[N_ROLES] = {0, 16, 80, 64, 64, 32, 64, 64, 32, 64, 64, 64, 64, 64, 32, 160, 32, 92, 92, 92, 16, 92, 184, 64, 64, 64, 64, 64, 64, 64, 16, 16};
 
 #define SIG1(D, Y)                                                                                                     \
     "v_fma_f32 %[t0], " Y ", %[a], %[b]\n v_mul_f32 %[t1], 0x3fb8aa3b, %[t0]\n v_add_f32 %[t1], 0x4b400000, %[t1]\n"      \
@@ -66,6 +66,14 @@ __global__ __launch_bounds__(1024) void kroles(Stamp* out, float* sink, const in
         for (int it = 0; it < n; ++it) {
             REP4(c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, x1, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, x1, c1, 0, 0, 0);
                  c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, x1, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, x1, c3, 0, 0, 0);)
+        }
+    } else if (role == R_MFMA2) {  // two accumulators alternating (the training kernels' tile product): dependent distance 2
+        for (int it = 0; it < n; ++it) {
+            REP8(c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, x1, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, x1, c1, 0, 0, 0);)
+        }
+    } else if (role == R_MFMA1) {  // one accumulator: every MFMA waits for its predecessor
+        for (int it = 0; it < n; ++it) {
+            REP16(c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, x1, c0, 0, 0, 0);)
         }
     } else if (role == R_MFMA4x4) {
         for (int it = 0; it < n; ++it) {
@@ -372,6 +380,22 @@ int main(int argc, char** argv) {
     iters[R_MFMA] = mf; iters[R_MFMA4x4] = 8000; iters[R_SIGMOID] = 5000; iters[R_SIGMOID2] = 2500; iters[R_RCP] = 8000;
     iters[R_PERMSWAP] = 8000; iters[R_LDSREAD] = 4000;
 
+    if (argc > 1 && !strcmp(argv[1], "chain")) {
+        printf("# part 5: f32 MFMA 16x16x4 chains: 4 / 2 / 1 accumulators per wave, 1, 2, 4 waves per SIMD (cycles per MFMA per SIMD)\n");
+        iters[R_MFMA2] = iters[R_MFMA1] = 4000;
+        for (int role : {R_MFMA, R_MFMA2, R_MFMA1}) {
+            for (int nw : {1, 2, 4}) {
+                int roles[4] = {IDLE, IDLE, IDLE, IDLE};
+                for (int k = 0; k < nw; ++k) roles[k] = role;
+                Result r = run(roles, iters, 5);
+                const double ops = (double)iters[role] * kOpsPerIter[role] * nw;
+                printf("%-9s waves/SIMD=%d  span=%9.0f cyc  cyc/MFMA/SIMD=%6.2f  (%.2f GHz)%s\n", kRoleName[role], nw, r.span_cyc,
+                       r.span_cyc / ops, r.ghz, r.placement_ok ? "" : " (!! placement)");
+                fflush(stdout);
+            }
+        }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "va")) {
         printf("# part 4: instruction forms of the 256-state Viterbi kernel; Salu beside VALU roles on the same SIMD\n");
         for (int role : {R_SALU, R_MIN3, R_CNDMASK, R_VCMP, R_FMAC, R_PKMUL, R_DPP}) {  // R_VCMPS did not finish in 300 s on the box: not run
