@@ -425,10 +425,20 @@ __global__ __launch_bounds__(64 * kCountWaves) void count_errors_kernel(const fl
         const float *dr = dec + r * dec_ld, *tr = tx + r * tx_ld;
         if ((((uintptr_t)dr | (uintptr_t)tr) & 15) == 0) {  // 16-B aligned rows: 4 symbols per load
             const int K4 = K >> 2;
-            for (int k = lane; k < K4; k += 64) {
-                const float4 a = reinterpret_cast<const float4 *>(dr)[k], c = reinterpret_cast<const float4 *>(tr)[k];
-                e += ((long long)a.x != (long long)c.x) + ((long long)a.y != (long long)c.y) +
-                     ((long long)a.z != (long long)c.z) + ((long long)a.w != (long long)c.w);  // .long() then eq
+            const float4 *d4 = reinterpret_cast<const float4 *>(dr), *t4 = reinterpret_cast<const float4 *>(tr);
+            for (int k0 = 0; k0 < K4; k0 += 256) {  // 8 loads in flight per lane (a 1000-symbol row is one trip)
+                float4 a[4], c[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + 64 * j + lane;
+                    const bool in = k < K4;
+                    a[j] = in ? d4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    c[j] = in ? t4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    e += ((long long)a[j].x != (long long)c[j].x) + ((long long)a[j].y != (long long)c[j].y) +
+                         ((long long)a[j].z != (long long)c[j].z) + ((long long)a[j].w != (long long)c[j].w);  // .long() then eq
             }
             for (int k = 4 * K4 + lane; k < K; k += 64) e += ((long long)dr[k] != (long long)tr[k]) ? 1 : 0;
         } else {
