@@ -957,6 +957,44 @@ def test_maml_kernel_vs_torch_double_backward(golden, dev, MAML, W):
     assert torch.allclose(trs[1].exp_avg, trs[0].exp_avg, rtol=1e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("L", [1, 2, 3, 5])
+def test_training_kernels_other_state_counts(dev, L):
+    """The one-launch training kernels at the other state counts their LDS image holds (S = 2, 4, 8: run-time S
+    instantiation; S = 32: two 16-state tiles per output product): online training (minibatch and full word) against torch
+    autograd + Adam, and the second-order MAML step against meta.meta_train_loop, same tolerances as at S = 16."""
+    S, T = 2 ** L, 136
+    rng = np.random.RandomState(L)
+    w = _rand_weights(S, rng)
+    tx = rng.randint(0, 2, (1, T)).astype(np.float32)
+    y = rng.normal(0, 1.5, (1, T)).astype(np.float32)
+    labels = mvn.calculate_states(L, torch.tensor(tx)).numpy()
+    for full_word, n_iter in ((False, 6), (True, 3)):
+        idx = np.stack([rng.choice(np.arange(1, T), 32, replace=False) for _ in range(n_iter)]).astype(np.int32)
+        ref_w, ref_loss = _torch_online_ref(w, y[0], labels, idx, 1e-3, n_iter, full_word)
+        det = _vnet_with(w, S, T, dev)
+        tr = mvn.OnlineTrainer(det, L)
+        loss = tr.online_training(torch.tensor(tx, device=dev), torch.tensor(y, device=dev), iterations=n_iter,
+                                  batch_idx=torch.tensor(idx, device=dev), full_word=full_word, return_loss=True)
+        assert np.allclose(_np(loss), ref_loss, rtol=2e-4, atol=1e-6), (S, full_word)
+        for i, p in enumerate(det.net.parameters()):
+            assert np.all(np.abs(_np(p) - ref_w[i]) <= 2e-5 + 1e-3 * np.abs(ref_w[i])), (S, full_word, i)
+    n_steps = 4
+    gen = torch.Generator(device=dev).manual_seed(11 + L)
+    rxw = torch.randn(5, T, generator=gen, device=dev)
+    txw = torch.randint(0, 2, (5, T), generator=gen, device=dev).float()
+    dets = [_vnet_with(w, S, T, dev) for _ in range(2)]
+    trs = [mvn.OnlineTrainer(d, L) for d in dets]
+    meta = mvn.META_VNETDetector(S, {"train": T, "val": T})
+    sup = torch.stack([torch.arange(k - 1, k, device=dev) for k in range(n_steps)])
+    qry = torch.arange(n_steps, device=dev)
+    ref_loss = [float(mvn.meta_train_loop(dets[0], meta, trs[0], rxw, txw, sup[k], qry[k:k + 1], 0.1, True)) for k in range(n_steps)]
+    loss = trs[1].maml_training(rxw, txw, sup, qry, 0.1, True, return_loss=True)
+    assert np.allclose(_np(loss), np.array(ref_loss), rtol=2e-4, atol=1e-6), S
+    for a, b in zip(dets[1].parameters(), dets[0].parameters()):
+        assert bool((torch.abs(a - b) <= 2e-5 + 1e-3 * torch.abs(b)).all()), S
+    assert torch.allclose(trs[1].exp_avg, trs[0].exp_avg, rtol=1e-3, atol=1e-6)
+
+
 def test_nonfinite_samples_like_reference(oracle, dev, monkeypatch):
     """NaN / +-inf received samples: the reference turns every branch cost of that symbol into NaN (ViterbiNet: the MLP
     propagates it; VA: (NaN - prior)^2), after which torch.min/argmin leave all metrics NaN and every later decision 0.
