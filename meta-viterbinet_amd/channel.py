@@ -114,3 +114,43 @@ def generate_words(n_words: int, block_length: int, h: np.ndarray, snr: float, m
                                                 _lib.current_stream(dev))
     _lib.check(rc, "mvn_generate_words_f32")
     return tx, y
+
+
+class ReferenceWordStream:
+    """Bit-exact twin of the reference's word source for small, reproducible runs: the two legacy NumPy
+    RandomState streams of ChannelModelDataset (trainer.py:90-91: noise seed 3450002, word seed 7860002;
+    channel_dataset.py:67 `randint(0, 2, (1, block_length))` per word, channel.py:31 `normal(0, 1, (1, T))` per word) drawn on
+    the host with NumPy's own MT19937 / polar-Gaussian code, then encoded (optional RS, channel_dataset.py:69) and sent
+    through the ISI-AWGN channel on the device by the replay kernel (mvn.transmit: float64 arithmetic, fp32 result --
+    bit-identical to the reference's received words, tests/test_gpu_parity.py::test_reference_word_stream_*).  The streams
+    persist across draw() calls like the dataset's RandomState members, so consecutive draws continue the reference's
+    sequence.  At-scale Monte-Carlo runs use mvn.generate_words (Philox, one kernel) instead."""
+
+    def __init__(self, block_length: int, memory_length: int, device, n_symbols: int = 0, noise_seed: int = 3450002,
+                 word_seed: int = 7860002):
+        self.block_length, self.memory_length, self.n_symbols = block_length, memory_length, n_symbols
+        self.device = device
+        self.random = np.random.RandomState(noise_seed)
+        self.word_rand_gen = np.random.RandomState(word_seed)
+
+    @property
+    def transmission_length(self) -> int:
+        return self.block_length + 8 * self.n_symbols  # trainer.py:196-198
+
+    def draw(self, n_words: int, h: np.ndarray, snr: float):
+        """`n_words` words through taps `h` [n_words or 1, L] (row i = estimate_channel(..., index=i)); returns
+        (b [n, block_length] fp32 bits, y [n, transmission_length] fp32), both on the device."""
+        import torch
+
+        from . import ecc
+
+        T = self.transmission_length
+        bits = np.empty((n_words, self.block_length), np.float32)
+        noise = np.empty((n_words, T), np.float64)
+        for i in range(n_words):  # word by word: the two streams advance exactly like get_snr_data's loop
+            bits[i] = self.word_rand_gen.randint(0, 2, size=(1, self.block_length))
+            noise[i] = self.random.normal(0, 1, (1, T))
+        b = torch.as_tensor(bits, device=self.device)
+        c = ecc.rs_encode(b, self.n_symbols) if self.n_symbols else b
+        y = transmit(c, h, snr, self.memory_length, torch.as_tensor(noise, device=self.device))
+        return b, y

@@ -580,6 +580,23 @@ def test_channel_transmit_replays_reference_draw(golden, dev, name):
     assert np.array_equal(_np(y), g[f"{name}_rx"])
 
 
+@pytest.mark.parametrize("name", ["L4_static", "L4_fading2", "L4_cost2100", "L8_static"])
+def test_reference_word_stream_replays_the_dataset(golden, dev, name):
+    """mvn.ReferenceWordStream = the reference's two RandomState streams + the replay channel kernel: from the seeds alone
+    it reproduces the transmitted AND received words the reference's ChannelModelDataset produced (G2), bit for bit, and a
+    second draw continues the streams like the dataset's RandomState members do."""
+    g = golden("g2_va")
+    L, frames, sub, T, snr, fdec, ttype = [int(v) for v in g[f"{name}_meta"]]
+    W = frames * sub
+    src = mvn.ReferenceWordStream(T, L, dev)
+    half = W // 2
+    h = np.asarray(g[f"{name}_h"])
+    b1, y1 = src.draw(half, h[:half], snr)
+    b2, y2 = src.draw(W - half, h[half:], snr)
+    assert np.array_equal(np.concatenate([_np(b1), _np(b2)]), g[f"{name}_tx"].astype(np.float32))
+    assert np.array_equal(np.concatenate([_np(y1), _np(y2)]), g[f"{name}_rx"])
+
+
 # ---------------------------------------------------------------- next #3: online (self-supervised) training in one launch
 def _torch_online_ref(w, y, labels, idx, lr, n_iter, full_word=False):
     """The reference's arithmetic for run_train_loop (trainer.py:492-505): torch autograd, CrossEntropyLoss(mean),
