@@ -46,7 +46,7 @@ typedef void *mvn_stream_t; /* hipStream_t */
 #define MVN_E_WORKSPACE (-5) /* workspace too small for one block */
 #define MVN_E_DEVICE (-6)    /* current device is not gfx950 */
 
-#define MVN_ABI_VERSION 2 /* 2: kernel-name queries take the buffers; mvn_va/vnet_decode_kernel_name */
+#define MVN_ABI_VERSION 3 /* 3: + training entry points with a workspace (one workgroup per chunk); 2: kernel-name queries */
 
 /* ABI version of the loaded library (== MVN_ABI_VERSION). */
 int mvn_version(void);
@@ -169,6 +169,20 @@ int mvn_vnet_online_train_f32(const float *y, const int32_t *labels, int32_t T, 
                               int32_t n_iter, float *W1, float *b1, float *W2, float *b2, float *W3, float *b3,
                               float *adam_m, float *adam_v, int64_t step0, float lr, float beta1, float beta2, float eps,
                               float *loss_out, int32_t S, mvn_stream_t stream);
+
+/*
+ * The same call spread over one workgroup per 32-sample chunk when every iteration uses the whole word (batch_idx == NULL,
+ * the Meta-ViterbiNet variant, metavnet_trainer.py:41-64): `workspace` = mvn_vnet_train_workspace_bytes(S) bytes of
+ * device memory, 16-byte aligned, used for the gradient exchange between the workgroups (contents irrelevant before and
+ * after; must not be shared by calls that may run concurrently).  Results are bit-identical to
+ * mvn_vnet_online_train_f32, which also serves every case this form does not (minibatch iterations, words of at most
+ * 32 symbols or more than 1024, workspace NULL or too small, MVN_TRAIN_GROUPS=0 in the environment).
+ */
+size_t mvn_vnet_train_workspace_bytes(int32_t n_states);
+int mvn_vnet_online_train_ws_f32(const float *y, const int32_t *labels, int32_t T, const int32_t *batch_idx, int32_t M,
+                                 int32_t n_iter, float *W1, float *b1, float *W2, float *b2, float *W3, float *b3,
+                                 float *adam_m, float *adam_v, int64_t step0, float lr, float beta1, float beta2, float eps,
+                                 float *loss_out, int32_t S, void *workspace, size_t workspace_bytes, mvn_stream_t stream);
 
 /*
  * n_steps online meta-learning steps of Meta-ViterbiNet in ONE launch: Trainer.meta_train_loop

@@ -399,6 +399,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 #include "rs_codec.inc"
 #include "online_train.inc"
 #include "maml_train.inc"
+#include "train_groups.inc"
 #include "word_gen.inc"
 
 // -------------------------------------------------------------------------------------------
@@ -885,6 +886,47 @@ int mvn_vnet_online_train_f32(const float *y, const int32_t *labels, int32_t T, 
     else if (S == 32) MVN_ONLINE_LAUNCH(32, 1);
     else MVN_ONLINE_LAUNCH(0, 2);
 #undef MVN_ONLINE_LAUNCH
+    return (int)hipGetLastError();
+}
+
+size_t mvn_vnet_train_workspace_bytes(int32_t S) {
+    if (!valid_states(S) || S > 32) return 0;
+    return train_groups_workspace_bytes(S, kTrainMaxGroups);
+}
+
+int mvn_vnet_online_train_ws_f32(const float *y, const int32_t *labels, int32_t T, const int32_t *batch_idx, int32_t M,
+                                 int32_t n_iter, float *W1, float *b1, float *W2, float *b2, float *W3, float *b3,
+                                 float *adam_m, float *adam_v, int64_t step0, float lr, float beta1, float beta2, float eps,
+                                 float *loss_out, int32_t S, void *workspace, size_t workspace_bytes, mvn_stream_t stream) {
+    const int groups = T >= 1 ? (T + kTrainChunk - 1) / kTrainChunk : 0;
+    // one workgroup per 32-sample chunk of a full-word iteration; everything else is the single-workgroup kernel's job
+    if (batch_idx || groups < 2 || groups > kTrainMaxGroups || !workspace || !valid_states(S) || S > 32 || n_iter < 1 ||
+        workspace_bytes < train_groups_workspace_bytes(S, groups) || env_is("MVN_TRAIN_GROUPS", '0'))
+        return mvn_vnet_online_train_f32(y, labels, T, batch_idx, M, n_iter, W1, b1, W2, b2, W3, b3, adam_m, adam_v, step0, lr,
+                                         beta1, beta2, eps, loss_out, S, stream);
+    if (step0 < 0) return MVN_E_DIMS;
+    if (!y || !labels || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !adam_m || !adam_v) return MVN_E_NULL;
+    if (reinterpret_cast<uintptr_t>(workspace) & 15) return MVN_E_WORKSPACE;
+    const size_t lds = online_train_lds_bytes(S);
+    static size_t lds_allowed[3] = {0, 0, 0};
+    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(GroupSync), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+#define MVN_ONLINE_GROUPS_LAUNCH(SC, SLOT)                                                                                  \
+    do {                                                                                                                   \
+        if (lds > lds_allowed[SLOT]) {                                                                                     \
+            e = hipFuncSetAttribute((const void *)online_train_groups_kernel<SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return (int)e;                                                                            \
+            lds_allowed[SLOT] = lds;                                                                                       \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(online_train_groups_kernel<SC>, dim3(groups), dim3(kTrainThreads), lds, (hipStream_t)stream, y,  \
+                           labels, T, n_iter, W1, b1, W2, b2, W3, b3, adam_m, adam_v, pow((double)beta1, (double)step0),    \
+                           pow((double)beta2, (double)step0), lr, beta1, beta2, eps, loss_out, S,                           \
+                           (int)online_train_lds_floats(S), (float *)workspace);                                           \
+    } while (0)
+    if (S == 16) MVN_ONLINE_GROUPS_LAUNCH(16, 0);
+    else if (S == 32) MVN_ONLINE_GROUPS_LAUNCH(32, 1);
+    else MVN_ONLINE_GROUPS_LAUNCH(0, 2);
+#undef MVN_ONLINE_GROUPS_LAUNCH
     return (int)hipGetLastError();
 }
 

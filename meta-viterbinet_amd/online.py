@@ -124,6 +124,14 @@ class OnlineTrainer:
         self.step += n
         return loss
 
+    def _workspace(self, S: int, dev) -> torch.Tensor:
+        """Device scratch for the gradient exchange of the one-workgroup-per-chunk training kernels
+        (mvn_vnet_train_workspace_bytes; 1.6 MB), allocated once per trainer."""
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.device != dev:
+            ws = self._ws = torch.empty(_lib.load().mvn_vnet_train_workspace_bytes(S), dtype=torch.uint8, device=dev)
+        return ws
+
     def select_batches(self, T: int, iterations: int) -> torch.Tensor:
         """`iterations` minibatches drawn like select_batch (trainer.py:542): torch.multinomial with weights
         arange(T) (sample 0 is never drawn), without replacement, all iterations in one call."""
@@ -156,12 +164,14 @@ class OnlineTrainer:
                 raise ValueError("ViterbiNet parameters must be contiguous fp32")
         loss = torch.empty(iterations, dtype=torch.float32, device=dev) if return_loss else None
         S = p[5].numel()
+        ws = self._workspace(S, dev)
         with torch.cuda.device(dev):
-            rc = _lib.load().mvn_vnet_online_train_f32(_lib.ptr(y), _lib.ptr(labels), T, _lib.ptr(idx), M, iterations,
-                                                       *[_lib.ptr(t.data) for t in p], _lib.ptr(self.exp_avg),
-                                                       _lib.ptr(self.exp_avg_sq), self.step, self.lr, self.betas[0],
-                                                       self.betas[1], self.eps, _lib.ptr(loss), S, _lib.current_stream(dev))
-        _lib.check(rc, "mvn_vnet_online_train_f32")
+            rc = _lib.load().mvn_vnet_online_train_ws_f32(_lib.ptr(y), _lib.ptr(labels), T, _lib.ptr(idx), M, iterations,
+                                                          *[_lib.ptr(t.data) for t in p], _lib.ptr(self.exp_avg),
+                                                          _lib.ptr(self.exp_avg_sq), self.step, self.lr, self.betas[0],
+                                                          self.betas[1], self.eps, _lib.ptr(loss), S, _lib.ptr(ws), ws.numel(),
+                                                          _lib.current_stream(dev))
+        _lib.check(rc, "mvn_vnet_online_train_ws_f32")
         self.step += iterations
         return loss
 

@@ -1012,6 +1012,30 @@ def test_training_kernels_other_state_counts(dev, L):
     assert torch.allclose(trs[1].exp_avg, trs[0].exp_avg, rtol=1e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("S,T", [(16, 136), (16, 33), (16, 1000), (32, 136), (4, 100)])
+def test_online_training_groups_equal_single_workgroup(dev, monkeypatch, S, T):
+    """Full-word online training spread over one workgroup per 32-sample chunk (mvn_vnet_online_train_ws_f32, the default for
+    words above 32 symbols) against the single-workgroup kernel (MVN_TRAIN_GROUPS=0): the gradient slots are summed in
+    chunk order, i.e. in the order the single workgroup accumulates them, so weights, both Adam moments and every
+    iteration's loss must be IDENTICAL bit for bit -- over two calls, so that the Adam state carries over."""
+    L = int(np.log2(S))
+    rng = np.random.RandomState(S + T)
+    w = _rand_weights(S, rng)
+    tx = torch.tensor(rng.randint(0, 2, (1, T)).astype(np.float32), device=dev)
+    y = torch.tensor(rng.normal(0, 1.5, (1, T)).astype(np.float32), device=dev)
+    out = []
+    for groups in ("1", "0"):
+        monkeypatch.setenv("MVN_TRAIN_GROUPS", groups)
+        det = _vnet_with(w, S, T, dev)
+        tr = mvn.OnlineTrainer(det, L)
+        l1 = tr.online_training(tx, y, iterations=7, full_word=True, return_loss=True)
+        l2 = tr.online_training(tx, y, iterations=5, full_word=True, return_loss=True)
+        out.append([p.detach().clone() for p in det.parameters()] + [tr.exp_avg.clone(), tr.exp_avg_sq.clone(), l1, l2])
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert bool(torch.isfinite(out[0][-1]).all())
+
+
 def test_nonfinite_samples_like_reference(oracle, dev, monkeypatch):
     """NaN / +-inf received samples: the reference turns every branch cost of that symbol into NaN (ViterbiNet: the MLP
     propagates it; VA: (NaN - prior)^2), after which torch.min/argmin leave all metrics NaN and every later decision 0.
