@@ -202,6 +202,18 @@ int mvn_vnet_maml_train_f32(const float *rx_words, const int32_t *labels, int32_
                             mvn_stream_t stream);
 
 /*
+ * The same steps with one workgroup per chunk of a pass (support gradient, query gradient, Hessian-vector product):
+ * `workspace` as for mvn_vnet_online_train_ws_f32 (gradient exchange + private copies of the Adam moments).  Bit-identical
+ * to mvn_vnet_maml_train_f32, which also serves the cases this form does not (a pass of more than 32 chunks or of one,
+ * workspace NULL or too small, MVN_TRAIN_GROUPS=0 in the environment).
+ */
+int mvn_vnet_maml_train_ws_f32(const float *rx_words, const int32_t *labels, int32_t T, const int32_t *support_idx, int32_t W,
+                               const int32_t *query_idx, int32_t n_steps, float *W1, float *b1, float *W2, float *b2,
+                               float *W3, float *b3, float *adam_m, float *adam_v, int64_t step0, float meta_lr,
+                               int32_t second_order, float lr, float beta1, float beta2, float eps, float *loss_out, int32_t S,
+                               void *workspace, size_t workspace_bytes, mvn_stream_t stream);
+
+/*
  * ISI-AWGN channel: ChannelModelDataset.transmit / ISIAWGNChannel.transmit,
  * python_code/channel/channel_dataset.py:71,87-95 + channel.py:12-35 + modulator.py:12:
  *   y[b,t] = sum_i h[b % Bh][L-1-i] * (1 - 2 c[b,t+i]) + sigma * w[b,t],   c = bits zero-padded past K,

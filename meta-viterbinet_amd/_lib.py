@@ -41,6 +41,8 @@ SIGNATURES = {
                                       ctypes.c_size_t, _vp]),
     "mvn_vnet_maml_train_f32": (ctypes.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32] + [_vp] * 8 +
                                 [_i64, ctypes.c_float, _i32] + [ctypes.c_float] * 4 + [_vp, _i32, _vp]),
+    "mvn_vnet_maml_train_ws_f32": (ctypes.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32] + [_vp] * 8 +
+                                   [_i64, ctypes.c_float, _i32] + [ctypes.c_float] * 4 + [_vp, _i32, _vp, ctypes.c_size_t, _vp]),
     "mvn_isi_awgn_transmit": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _i64, ctypes.c_double, _vp, _i64, _i64,
                                              _i32, _i32, _vp]),
     "mvn_generate_words_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, ctypes.c_double, ctypes.c_uint64, _i64, _i32, _i32, _vp]),

@@ -891,7 +891,7 @@ int mvn_vnet_online_train_f32(const float *y, const int32_t *labels, int32_t T, 
 
 size_t mvn_vnet_train_workspace_bytes(int32_t S) {
     if (!valid_states(S) || S > 32) return 0;
-    return train_groups_workspace_bytes(S, kTrainMaxGroups);
+    return maml_groups_workspace_bytes(S, kTrainMaxGroups);  // the larger of the two kernels' needs
 }
 
 int mvn_vnet_online_train_ws_f32(const float *y, const int32_t *labels, int32_t T, const int32_t *batch_idx, int32_t M,
@@ -958,6 +958,46 @@ int mvn_vnet_maml_train_f32(const float *rx_words, const int32_t *labels, int32_
     else if (S == 32) MVN_MAML_LAUNCH(32, 1);
     else MVN_MAML_LAUNCH(0, 2);
 #undef MVN_MAML_LAUNCH
+    return (int)hipGetLastError();
+}
+
+int mvn_vnet_maml_train_ws_f32(const float *rx_words, const int32_t *labels, int32_t T, const int32_t *support_idx, int32_t W,
+                               const int32_t *query_idx, int32_t n_steps, float *W1, float *b1, float *W2, float *b2,
+                               float *W3, float *b3, float *adam_m, float *adam_v, int64_t step0, float meta_lr,
+                               int32_t second_order, float lr, float beta1, float beta2, float eps, float *loss_out, int32_t S,
+                               void *workspace, size_t workspace_bytes, mvn_stream_t stream) {
+    // one workgroup per chunk of the largest pass: the Hessian pass's 16-sample chunks when second order
+    const long long n_sup = (long long)W * T;
+    const long long groups_ll = (T >= 1 && W >= 1) ? (second_order ? (n_sup + kHvRows - 1) / kHvRows : (n_sup + kTrainChunk - 1) / kTrainChunk) : 0;
+    const int groups = groups_ll > kTrainMaxGroups ? 0 : (int)groups_ll;
+    if (groups < 2 || !workspace || !valid_states(S) || S > 32 || n_steps < 1 ||
+        workspace_bytes < maml_groups_workspace_bytes(S, groups) || env_is("MVN_TRAIN_GROUPS", '0'))
+        return mvn_vnet_maml_train_f32(rx_words, labels, T, support_idx, W, query_idx, n_steps, W1, b1, W2, b2, W3, b3, adam_m,
+                                       adam_v, step0, meta_lr, second_order, lr, beta1, beta2, eps, loss_out, S, stream);
+    if (step0 < 0) return MVN_E_DIMS;
+    if (!rx_words || !labels || !support_idx || !query_idx || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !adam_m || !adam_v)
+        return MVN_E_NULL;
+    if (reinterpret_cast<uintptr_t>(workspace) & 15) return MVN_E_WORKSPACE;
+    const size_t lds = maml_train_lds_floats(S) * sizeof(float);
+    static size_t lds_allowed[3] = {0, 0, 0};
+    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(GroupSync), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+#define MVN_MAML_GROUPS_LAUNCH(SC, SLOT)                                                                                   \
+    do {                                                                                                                   \
+        if (lds > lds_allowed[SLOT]) {                                                                                     \
+            e = hipFuncSetAttribute((const void *)maml_train_groups_kernel<SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return (int)e;                                                                            \
+            lds_allowed[SLOT] = lds;                                                                                       \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(maml_train_groups_kernel<SC>, dim3(groups), dim3(kTrainThreads), lds, (hipStream_t)stream,       \
+                           rx_words, labels, T, support_idx, W, query_idx, n_steps, W1, b1, W2, b2, W3, b3, adam_m, adam_v, \
+                           pow((double)beta1, (double)step0), pow((double)beta2, (double)step0), meta_lr, second_order, lr, \
+                           beta1, beta2, eps, loss_out, S, (int)maml_train_lds_floats(S), (float *)workspace);             \
+    } while (0)
+    if (S == 16) MVN_MAML_GROUPS_LAUNCH(16, 0);
+    else if (S == 32) MVN_MAML_GROUPS_LAUNCH(32, 1);
+    else MVN_MAML_GROUPS_LAUNCH(0, 2);
+#undef MVN_MAML_GROUPS_LAUNCH
     return (int)hipGetLastError();
 }
 

@@ -114,19 +114,20 @@ class OnlineTrainer:
             if not t.data.is_contiguous() or t.dtype != torch.float32:
                 raise ValueError("ViterbiNet parameters must be contiguous fp32")
         loss = torch.empty(n, dtype=torch.float32, device=dev) if return_loss else None
+        ws = self._workspace(p[5].numel(), dev)
         with torch.cuda.device(dev):
-            rc = _lib.load().mvn_vnet_maml_train_f32(_lib.ptr(rx), _lib.ptr(labels), T, _lib.ptr(sup), W, _lib.ptr(qry), n,
-                                                     *[_lib.ptr(t.data) for t in p], _lib.ptr(self.exp_avg),
-                                                     _lib.ptr(self.exp_avg_sq), self.step, meta_lr, 1 if MAML else 0,
-                                                     self.lr, self.betas[0], self.betas[1], self.eps, _lib.ptr(loss),
-                                                     p[5].numel(), _lib.current_stream(dev))
-        _lib.check(rc, "mvn_vnet_maml_train_f32")
+            rc = _lib.load().mvn_vnet_maml_train_ws_f32(_lib.ptr(rx), _lib.ptr(labels), T, _lib.ptr(sup), W, _lib.ptr(qry), n,
+                                                        *[_lib.ptr(t.data) for t in p], _lib.ptr(self.exp_avg),
+                                                        _lib.ptr(self.exp_avg_sq), self.step, meta_lr, 1 if MAML else 0,
+                                                        self.lr, self.betas[0], self.betas[1], self.eps, _lib.ptr(loss),
+                                                        p[5].numel(), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev))
+        _lib.check(rc, "mvn_vnet_maml_train_ws_f32")
         self.step += n
         return loss
 
     def _workspace(self, S: int, dev) -> torch.Tensor:
         """Device scratch for the gradient exchange of the one-workgroup-per-chunk training kernels
-        (mvn_vnet_train_workspace_bytes; 1.6 MB), allocated once per trainer."""
+        (mvn_vnet_train_workspace_bytes; about 3 MB), allocated once per trainer."""
         ws = getattr(self, "_ws", None)
         if ws is None or ws.device != dev:
             ws = self._ws = torch.empty(_lib.load().mvn_vnet_train_workspace_bytes(S), dtype=torch.uint8, device=dev)

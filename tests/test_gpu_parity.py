@@ -1036,6 +1036,33 @@ def test_online_training_groups_equal_single_workgroup(dev, monkeypatch, S, T):
     assert bool(torch.isfinite(out[0][-1]).all())
 
 
+@pytest.mark.parametrize("S,T,W,MAML", [(16, 136, 1, True), (16, 136, 2, True), (16, 136, 1, False), (32, 100, 1, True), (8, 136, 1, True)])
+def test_maml_training_groups_equal_single_workgroup(dev, monkeypatch, S, T, W, MAML):
+    """The meta-learning steps with one workgroup per chunk of a pass (mvn_vnet_maml_train_ws_f32, the default) against the
+    single-workgroup kernel (MVN_TRAIN_GROUPS=0): weights, Adam moments and the reported query losses identical bit for bit,
+    over two calls (the Adam state carries over)."""
+    L = int(np.log2(S))
+    rng = np.random.RandomState(S + T + W)
+    w = _rand_weights(S, rng)
+    gen = torch.Generator(device=dev).manual_seed(3 + W)
+    rxw = torch.randn(6, T, generator=gen, device=dev)
+    txw = torch.randint(0, 2, (6, T), generator=gen, device=dev).float()
+    n_steps = 5
+    sup = torch.stack([torch.arange(k, k + W, device=dev) % 6 for k in range(n_steps)])
+    qry = (torch.arange(n_steps, device=dev) + W) % 6
+    out = []
+    for groups in ("1", "0"):
+        monkeypatch.setenv("MVN_TRAIN_GROUPS", groups)
+        det = _vnet_with(w, S, T, dev)
+        tr = mvn.OnlineTrainer(det, L)
+        l1 = tr.maml_training(rxw, txw, sup, qry, 0.1, MAML, return_loss=True)
+        l2 = tr.maml_training(rxw, txw, sup[:2], qry[:2], 0.1, MAML, return_loss=True)
+        out.append([p.detach().clone() for p in det.parameters()] + [tr.exp_avg.clone(), tr.exp_avg_sq.clone(), l1, l2])
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert bool(torch.isfinite(out[0][-1]).all()) and bool(torch.isfinite(out[0][0]).all())
+
+
 def test_nonfinite_samples_like_reference(oracle, dev, monkeypatch):
     """NaN / +-inf received samples: the reference turns every branch cost of that symbol into NaN (ViterbiNet: the MLP
     propagates it; VA: (NaN - prior)^2), after which torch.min/argmin leave all metrics NaN and every later decision 0.
