@@ -282,9 +282,9 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
                           "200 full-word iterations per block, every 5 blocks 20 x <=10 MAML steps)",
                 "n_gpus": world, "ms": ms4, "ms_per_block": ms4 / N, "blocks_per_s": world * N / (ms4 * 1e-3),
                 "symbols_per_s": world * N * T2 / (ms4 * 1e-3), "mean_ser_by_trial": [float(v) for v in np.nanmean(rep4, axis=1)],
-                "kernel": "maml_train_kernel + online_train_kernel + " + kfused,
+                "kernel": "maml_train_groups_kernel + online_train_groups_kernel + " + kfused,
                 "what": f"{world} independent trial(s) (replicas: block k's weights depend on the blocks before it), one all_gather of ser_by_word[300]",
-                "roofline": None, "note": "two single-workgroup training kernels per block: bound by one CU's LDS / issue rate, see DESIGN.md 5.5"})
+                "roofline": None, "note": "training passes run one workgroup per 32-sample chunk (5 / 9 CUs per word), gradients exchanged through a workspace with one device-wide barrier per pass: latency-bound, see DESIGN.md 5.6"})
     return out
 
 
