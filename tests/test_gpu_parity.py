@@ -1063,6 +1063,42 @@ def test_maml_training_groups_equal_single_workgroup(dev, monkeypatch, S, T, W, 
     assert bool(torch.isfinite(out[0][-1]).all()) and bool(torch.isfinite(out[0][0]).all())
 
 
+def test_training_groups_under_a_busy_device(golden, dev):
+    """The device-wide barrier of the one-workgroup-per-chunk training kernels while another stream keeps every CU busy with
+    full-chip decode launches (their workgroups hold most of each CU's LDS, so the training workgroups become resident one
+    by one as CUs drain): same bits as on an idle device."""
+    g7 = golden("g7_by_word")
+    w = [g7[f"w{i}"] for i in range(6)]
+    S, T, L = 16, 136, 4
+    gen = torch.Generator(device=dev).manual_seed(9)
+    rxw = torch.randn(6, T, generator=gen, device=dev)
+    txw = torch.randint(0, 2, (6, T), generator=gen, device=dev).float()
+    sup = torch.arange(12, device=dev).reshape(12, 1) % 6
+    qry = (torch.arange(12, device=dev) + 1) % 6
+    big = _vnet_with(w, S, 1000, dev)
+    yb = torch.randn(20000, 1000, generator=gen, device=dev)
+
+    def train(busy):
+        det = _vnet_with(w, S, T, dev)
+        tr = mvn.OnlineTrainer(det, L)
+        side = torch.cuda.Stream(device=dev)
+        if busy:
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(12):  # ~30 ms of back-to-back 20 000-block launches
+                    big(yb, "val")
+        loss = tr.maml_training(rxw, txw, sup, qry, 0.1, True, return_loss=True)
+        l2 = tr.online_training(txw[:1], rxw[:1], iterations=20, full_word=True, return_loss=True)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        return [p.detach().clone() for p in det.parameters()] + [tr.exp_avg.clone(), loss, l2]
+
+    idle, busy = train(False), train(True)
+    for a, b in zip(idle, busy):
+        assert torch.equal(a, b)
+    assert bool(torch.isfinite(busy[0]).all())
+
+
 def test_nonfinite_samples_like_reference(oracle, dev, monkeypatch):
     """NaN / +-inf received samples: the reference turns every branch cost of that symbol into NaN (ViterbiNet: the MLP
     propagates it; VA: (NaN - prior)^2), after which torch.min/argmin leave all metrics NaN and every later decision 0.
