@@ -686,6 +686,21 @@ int dispatch_sweep(const float *src, int64_t src_ld, const float *priors, int64_
 
 bool valid_states(int S) { return S >= 2 && S <= 256 && (S & (S - 1)) == 0; }
 
+// CUs of the current device (cached per device): the one-workgroup-per-chunk training kernels need one CU per workgroup to be
+// resident at once (each workgroup takes most of a CU's LDS)
+int current_device_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
+
 }  // namespace
 
 // =============================================================================================
@@ -901,7 +916,7 @@ int mvn_vnet_online_train_ws_f32(const float *y, const int32_t *labels, int32_t 
     const int groups = T >= 1 ? (T + kTrainChunk - 1) / kTrainChunk : 0;
     // one workgroup per 32-sample chunk of a full-word iteration; everything else is the single-workgroup kernel's job
     if (batch_idx || groups < 2 || groups > kTrainMaxGroups || !workspace || !valid_states(S) || S > 32 || n_iter < 1 ||
-        workspace_bytes < train_groups_workspace_bytes(S, groups) || env_is("MVN_TRAIN_GROUPS", '0'))
+        workspace_bytes < train_groups_workspace_bytes(S, groups) || env_is("MVN_TRAIN_GROUPS", '0') || groups > current_device_cus())
         return mvn_vnet_online_train_f32(y, labels, T, batch_idx, M, n_iter, W1, b1, W2, b2, W3, b3, adam_m, adam_v, step0, lr,
                                          beta1, beta2, eps, loss_out, S, stream);
     if (step0 < 0) return MVN_E_DIMS;
@@ -971,7 +986,7 @@ int mvn_vnet_maml_train_ws_f32(const float *rx_words, const int32_t *labels, int
     const long long groups_ll = (T >= 1 && W >= 1) ? (second_order ? (n_sup + kHvRows - 1) / kHvRows : (n_sup + kTrainChunk - 1) / kTrainChunk) : 0;
     const int groups = groups_ll > kTrainMaxGroups ? 0 : (int)groups_ll;
     if (groups < 2 || !workspace || !valid_states(S) || S > 32 || n_steps < 1 ||
-        workspace_bytes < maml_groups_workspace_bytes(S, groups) || env_is("MVN_TRAIN_GROUPS", '0'))
+        workspace_bytes < maml_groups_workspace_bytes(S, groups) || env_is("MVN_TRAIN_GROUPS", '0') || groups > current_device_cus())
         return mvn_vnet_maml_train_f32(rx_words, labels, T, support_idx, W, query_idx, n_steps, W1, b1, W2, b2, W3, b3, adam_m,
                                        adam_v, step0, meta_lr, second_order, lr, beta1, beta2, eps, loss_out, S, stream);
     if (step0 < 0) return MVN_E_DIMS;
