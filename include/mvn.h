@@ -46,7 +46,9 @@ typedef void *mvn_stream_t; /* hipStream_t */
 #define MVN_E_WORKSPACE (-5) /* workspace too small for one block */
 #define MVN_E_DEVICE (-6)    /* current device is not gfx950 */
 
-#define MVN_ABI_VERSION 3 /* 3: + training entry points with a workspace (one workgroup per chunk); 2: kernel-name queries */
+#define MVN_E_BARRIER (-7)   /* (status words only) a training launch abandoned its device-wide barrier */
+
+#define MVN_ABI_VERSION 4 /* 4: + trial-batched training / by-word step, status words; 3: training with a workspace; 2: kernel-name queries */
 
 /* ABI version of the loaded library (== MVN_ABI_VERSION). */
 int mvn_version(void);
@@ -179,10 +181,17 @@ int mvn_vnet_online_train_f32(const float *y, const int32_t *labels, int32_t T, 
  * 32 symbols or more than 1024, workspace NULL or too small, MVN_TRAIN_GROUPS=0 in the environment).
  */
 size_t mvn_vnet_train_workspace_bytes(int32_t n_states);
+/* status: device int32[1] or NULL.  The workgroups of this form meet at a device-wide barrier whose wait is bounded (a launch
+ * that cannot become resident must not hang the device).  If a wait is abandoned the weights come back as NaN AND *status is
+ * set to 1 (the caller zeroes it; it is never written otherwise): check it wherever the host next synchronises -- the
+ * counterpart of the reference's NaN-loss guard, trainer.py:496-498.  Concurrent launches of this form (different streams,
+ * different workspaces) are safe while their combined workgroups (one per 32-sample chunk) fit the device's CUs; to run many
+ * words at once use the *_trials_* entry points below, which put them into ONE launch. */
 int mvn_vnet_online_train_ws_f32(const float *y, const int32_t *labels, int32_t T, const int32_t *batch_idx, int32_t M,
                                  int32_t n_iter, float *W1, float *b1, float *W2, float *b2, float *W3, float *b3,
                                  float *adam_m, float *adam_v, int64_t step0, float lr, float beta1, float beta2, float eps,
-                                 float *loss_out, int32_t S, void *workspace, size_t workspace_bytes, mvn_stream_t stream);
+                                 float *loss_out, int32_t S, void *workspace, size_t workspace_bytes, int32_t *status,
+                                 mvn_stream_t stream);
 
 /*
  * n_steps online meta-learning steps of Meta-ViterbiNet in ONE launch: Trainer.meta_train_loop
@@ -211,7 +220,72 @@ int mvn_vnet_maml_train_ws_f32(const float *rx_words, const int32_t *labels, int
                                const int32_t *query_idx, int32_t n_steps, float *W1, float *b1, float *W2, float *b2,
                                float *W3, float *b3, float *adam_m, float *adam_v, int64_t step0, float meta_lr,
                                int32_t second_order, float lr, float beta1, float beta2, float eps, float *loss_out, int32_t S,
-                               void *workspace, size_t workspace_bytes, mvn_stream_t stream);
+                               void *workspace, size_t workspace_bytes, int32_t *status, mvn_stream_t stream);
+
+/*
+ * R independent trials of the two training calls above in ONE launch sequence (the evaluations with online
+ * training between blocks do not shard within a trial, so the parallel axis is the (SNR x seed x method) grid the reference
+ * walks serially, python_code/plotters/plotter_main.py:117-149; a trial alone occupies 1-9 of the 256 CUs).  Every trial
+ * has its own weights, Adam state, word(s), draws and step count, described by one mvn_train_trial_t in a DEVICE array;
+ * what is common to the launch (T, M / W, the optimizer's constants, S) is passed by value.  gridDim = (chunks, trials): a
+ * trial's workgroups only ever synchronise with each other (per-trial barrier counter in the workspace), trials with n = 0
+ * exit at once, and a launch never holds more workgroups than the device has CUs (more trials = more launches on `stream`).
+ * Per trial the results are bit-identical to the single-trial entry points.
+ */
+typedef struct mvn_train_trial {
+    const float *y;           /* online: the word [T]; maml: the buffered received words [Nw, T] */
+    const int32_t *labels;    /* online: [T]; maml: [Nw, T] (calculate_states of the buffered label words) */
+    const int32_t *idx;       /* online: batch_idx [n, M] or NULL = whole word; maml: support_idx [n, W] */
+    const int32_t *query_idx; /* maml: [n]; online: unused */
+    const float *w_in[6];     /* W1, b1, W2, b2, W3, b3 read when the trial starts (e.g. the saved detector, trainer.py:275) */
+    float *w_out[6];          /* ... written when it ends (may alias w_in) */
+    float *w_out2[6];         /* optional second copy of the result (all six NULL: none) */
+    float *adam_m, *adam_v;   /* [P] exp_avg / exp_avg_sq, updated in place */
+    float *loss_out;          /* [n] or NULL */
+    int32_t *status;          /* int32[1] or NULL: set to 1 if the trial's barrier wait was abandoned (weights = NaN) */
+    double b1pow, b2pow;      /* (double)beta1 ** step0, (double)beta2 ** step0: Adam steps this trial has already taken */
+    int32_t n;                /* iterations (online) / meta-learning steps (maml) of this trial; 0 = skip the trial */
+    int32_t reserved;
+} mvn_train_trial_t;
+
+/* Device workspace for R trials of words of T symbols (W support words for the meta-learning step); 0 when the shapes run
+ * on one workgroup per trial (minibatch iterations, T <= 32) and need none. */
+size_t mvn_vnet_train_trials_workspace_bytes(int32_t n_states, int32_t T, int32_t W, int32_t R);
+/* M = 0: every iteration uses the whole word (idx NULL in every trial); M > 0: minibatches of M samples (idx given). */
+int mvn_vnet_online_train_trials_f32(const mvn_train_trial_t *trials, int32_t R, int32_t T, int32_t M, float lr, float beta1,
+                                     float beta2, float eps, int32_t S, void *workspace, size_t workspace_bytes,
+                                     mvn_stream_t stream);
+int mvn_vnet_maml_train_trials_f32(const mvn_train_trial_t *trials, int32_t R, int32_t T, int32_t W, float meta_lr,
+                                   int32_t second_order, float lr, float beta1, float beta2, float eps, int32_t S,
+                                   void *workspace, size_t workspace_bytes, mvn_stream_t stream);
+
+/*
+ * One block step of Trainer.eval_by_word (python_code/trainers/trainer.py:292-316 and the buffer entry of :322-324) for R
+ * words in ONE launch, 16 states, Reed-Solomon outer code with nsym <= 8 parity bytes:
+ *   data step (pilot = 0): dec = VNETDetector.forward(rx,'val'); msg = RS-decode(dec); nerr = bit errors of msg against tx;
+ *                          enc = RS-encode(msg);
+ *   pilot step (pilot = 1): enc = RS-encode(tx); nerr = 0; dec and msg are not written (the reference detects the pilot too
+ *                          but never uses the result);
+ *   label_word = dec if nerr > 0 else enc (what the reference pushes into its buffer), labels = its trellis states
+ *   (calculate_states, utils/trellis_utils.py:33-46).
+ * Word r uses the weights W1 + r * w_stride[0], b1 + r * w_stride[1], ... (w_stride: HOST int64[6], NULL = one set for all):
+ * R independent trials advance one block per launch; R = 1 is the reference's sequential pattern (one launch instead of
+ * detect, RS decode, count, RS encode).
+ *   rx [R, rx_ld >= T]; tx [R, tx_ld >= T - 8 nsym] message bits; dec / enc / label_word [R, ld >= T] or NULL;
+ *   msg [R, msg_ld >= T - 8 nsym] or NULL; labels int32 [R, lab_ld >= T] or NULL; nerr int32 [R] or NULL.
+ * T a multiple of 8, T <= 1024, T / 8 > nsym.  Decisions, decoded and encoded words are bit-identical to
+ * mvn_vnet_decode_f32 + mvn_rs_decode_bits_f32 + mvn_rs_encode_bits_f32.  Returns MVN_E_STATES for S != 16 and MVN_E_DIMS
+ * for nsym > 8 (use the separate entry points there).
+ */
+int mvn_vnet_byword_step_f32(const float *rx, int64_t rx_ld, const float *tx, int64_t tx_ld, const float *W1, const float *b1,
+                             const float *W2, const float *b2, const float *W3, const float *b3, const int64_t *w_stride,
+                             float *dec, int64_t dec_ld, float *msg, int64_t msg_ld, float *enc, int64_t enc_ld,
+                             float *label_word, int64_t lw_ld, int32_t *labels, int64_t lab_ld, int32_t *nerr, int64_t R,
+                             int32_t T, int32_t nsym, int32_t pilot, int32_t S, mvn_stream_t stream);
+
+/* The MVN_* environment switches (A/B variants of the kernels) are read once per process; a caller that
+ * changes them afterwards (the test-suite does) calls this to have them read again. */
+void mvn_reload_switches(void);
 
 /*
  * ISI-AWGN channel: ChannelModelDataset.transmit / ISIAWGNChannel.transmit,

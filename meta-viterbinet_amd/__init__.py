@@ -8,6 +8,7 @@ from .harness import (data_indices, detect_by_word, eval_by_word, eval_counters,
                       single_eval_at_point, synthetic_words)
 from .meta import GraphedMetaStep, copy_model, meta_train_loop
 from .online import OnlineTrainer
+from .trials import TrialBank, TrialDraws, eval_by_word_batched
 from .metrics import calculate_error_rates, count_errors, rates_from_counters
 from .trellis import acs_block, acs_sweep, calculate_states, create_transition_table
 
@@ -17,5 +18,5 @@ __all__ = [
     "calculate_error_rates", "count_errors", "rates_from_counters",
     "estimate_channel", "BPSKModulator", "transmit", "generate_words", "ReferenceWordStream", "rs_encode", "rs_decode", "OnlineTrainer", "meta_train_loop", "GraphedMetaStep", "copy_model",
     "shard_range", "data_indices", "synthetic_words", "eval_counters", "single_eval_at_point",
-    "sharded_eval", "detect_by_word", "eval_by_word", "replica_eval",
+    "sharded_eval", "detect_by_word", "eval_by_word", "replica_eval", "TrialBank", "TrialDraws", "eval_by_word_batched",
 ]

@@ -9,7 +9,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVN_LIB_PATH", os.path.join(_PKG, "libmvn_hip.so"))  # override: A/B builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -38,11 +38,18 @@ SIGNATURES = {
     "mvn_vnet_train_workspace_bytes": (ctypes.c_size_t, [_i32]),
     "mvn_vnet_online_train_ws_f32": (ctypes.c_int, [_vp, _vp, _i32, _vp, _i32, _i32] + [_vp] * 8 +
                                      [_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _i32, _vp,
-                                      ctypes.c_size_t, _vp]),
+                                      ctypes.c_size_t, _vp, _vp]),
     "mvn_vnet_maml_train_f32": (ctypes.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32] + [_vp] * 8 +
                                 [_i64, ctypes.c_float, _i32] + [ctypes.c_float] * 4 + [_vp, _i32, _vp]),
     "mvn_vnet_maml_train_ws_f32": (ctypes.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32] + [_vp] * 8 +
-                                   [_i64, ctypes.c_float, _i32] + [ctypes.c_float] * 4 + [_vp, _i32, _vp, ctypes.c_size_t, _vp]),
+                                   [_i64, ctypes.c_float, _i32] + [ctypes.c_float] * 4 + [_vp, _i32, _vp, ctypes.c_size_t, _vp, _vp]),
+    "mvn_vnet_train_trials_workspace_bytes": (ctypes.c_size_t, [_i32, _i32, _i32, _i32]),
+    "mvn_vnet_online_train_trials_f32": (ctypes.c_int, [_vp, _i32, _i32, _i32] + [ctypes.c_float] * 4 + [_i32, _vp, ctypes.c_size_t, _vp]),
+    "mvn_vnet_maml_train_trials_f32": (ctypes.c_int, [_vp, _i32, _i32, _i32, ctypes.c_float, _i32] + [ctypes.c_float] * 4 +
+                                       [_i32, _vp, ctypes.c_size_t, _vp]),
+    "mvn_vnet_byword_step_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64] + [_vp] * 6 + [ctypes.POINTER(ctypes.c_int64)] +
+                                 [_vp, _i64] * 4 + [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "mvn_reload_switches": (None, []),
     "mvn_isi_awgn_transmit": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _i64, ctypes.c_double, _vp, _i64, _i64,
                                              _i32, _i32, _vp]),
     "mvn_generate_words_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, ctypes.c_double, ctypes.c_uint64, _i64, _i32, _i32, _vp]),
@@ -75,6 +82,12 @@ def load():
             raise MvnError(f"libmvn_hip.so ABI {lib.mvn_version()} != expected {ABI_VERSION}")
         _lib = lib
     return _lib
+
+
+def reload_switches():
+    """The library reads its MVN_* environment switches once per process; call this after changing one in-process."""
+    if _lib is not None:
+        _lib.mvn_reload_switches()
 
 
 def check(rc: int, what: str):

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <math.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "../../include/mvn.h"
@@ -397,6 +398,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 #include "va256_wave.inc"
 #include "sweep_inplace.inc"
 #include "rs_codec.inc"
+#include "byword_step.inc"
 #include "online_train.inc"
 #include "maml_train.inc"
 #include "train_groups.inc"
@@ -506,25 +508,68 @@ __global__ __launch_bounds__(256) void isi_awgn_kernel(const float *__restrict__
     y[b * y_ld + t] = (float)acc;
 }
 
-// MVN_UNFUSED=1 forces the two-kernel ViterbiNet path (MLP -> logits -> sweep) for testing.
-bool unfused_forced() {
-    const char *e = getenv("MVN_UNFUSED");
-    return e && e[0] == '1';
+// The MVN_* switches (A/B runs, cross-checks in the tests).  Only the first character of a value matters.
+// They are read from the environment ONCE per process -- the by-word evaluation calls into the library every few
+// microseconds -- and again when the caller asks (mvn_reload_switches: the test-suite flips them between calls).
+enum Switch { SW_UNFUSED, SW_COOP, SW_FUSEDN, SW_GENERIC_SWEEP, SW_VA256, SW_VA_INPLACE, SW_VA16, SW_SWEEP_INPLACE, SW_SWEEP16,
+              SW_TRAIN_GROUPS, SW_COUNT };
+const char *const kSwitchNames[SW_COUNT] = {"MVN_UNFUSED", "MVN_COOP", "MVN_FUSEDN", "MVN_GENERIC_SWEEP", "MVN_VA256",
+                                            "MVN_VA_INPLACE", "MVN_VA16", "MVN_SWEEP_INPLACE", "MVN_SWEEP16", "MVN_TRAIN_GROUPS"};
+char g_switch[SW_COUNT];
+bool g_switches_loaded = false;
+void load_switches() {
+    for (int i = 0; i < SW_COUNT; ++i) {
+        const char *e = getenv(kSwitchNames[i]);
+        g_switch[i] = e ? e[0] : 0;
+    }
+    g_switches_loaded = true;
 }
+inline char sw(Switch i) {
+    if (!g_switches_loaded) load_switches();
+    return g_switch[i];
+}
+
+// MVN_UNFUSED=1 forces the two-kernel ViterbiNet path (MLP -> logits -> sweep) for testing.
+bool unfused_forced() { return sw(SW_UNFUSED) == '1'; }
 
 // Small batches take the cooperative kernel (vnet16_coop.inc); MVN_COOP=0|1 pins the choice (A/B runs, tests).
 bool coop_selected(int64_t B, int T) {
     if (T > kCoopMaxT) return false;
-    const char *e = getenv("MVN_COOP");
-    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    const char e = sw(SW_COOP);
+    if (e == '0' || e == '1') return e == '1';
     return B <= kCoopMaxBlocks;
 }
 
-// MVN_FUSEDN=2|4 pins the tiles per super-tile of the fused kernel (vnet16_fusedn.inc); default 2 (5 waves/SIMD).
+// MVN_FUSEDN=2|4 pins the tiles per super-tile of the fused kernel (vnet16_fusedn.inc); default 2 (6 waves/SIMD).
 int fusedn_tiles() {
-    const char *e = getenv("MVN_FUSEDN");
-    if (e && (e[0] == '2' || e[0] == '4')) return e[0] - '0';
+    const char e = sw(SW_FUSEDN);
+    if (e == '2' || e == '4') return e - '0';
     return kFusedNDefault;
+}
+
+// The opt-in to more than 64 KB of dynamic LDS is per function (and device): raised once, remembered
+int ensure_dynamic_lds(const void *fn, size_t bytes) {
+    struct Entry {
+        const void *fn;
+        int dev;
+        size_t bytes;
+    };
+    static Entry seen[64];
+    static int n_seen = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    for (int i = 0; i < n_seen; ++i)
+        if (seen[i].fn == fn && seen[i].dev == dev) {
+            if (seen[i].bytes >= bytes) return 0;
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e != hipSuccess) return (int)e;
+            seen[i].bytes = bytes;
+            return 0;
+        }
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    if (n_seen < 64) seen[n_seen++] = Entry{fn, dev, bytes};
+    return 0;
 }
 
 // counters[1] += K * (#counted rows), counters[3] += #counted rows  (rows with mask != 0, or all B when mask is NULL)
@@ -553,14 +598,8 @@ int launch_vnet16_fused(const float *y, int64_t y_ld, const float *W1, const flo
                         const unsigned char *row_mask, unsigned long long *counters, hipStream_t st) {
     if (coop_selected(B, T)) {  // small batch: a 16-wave workgroup per block (MLP tiles in parallel, one sweeping wave)
         const size_t dyn = (size_t)((T + 15) / 16) * 1024;
-        static size_t lds_allowed[2] = {0, 0};
-        const int slot = logits_out ? 1 : 0;
-        if (dyn > lds_allowed[slot]) {
-            const void *fn = logits_out ? (const void *)vnet16_coop_kernel<true> : (const void *)vnet16_coop_kernel<false>;
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kCoopMaxT / 16 * 1024));
-            if (e != hipSuccess) return (int)e;
-            lds_allowed[slot] = (size_t)(kCoopMaxT / 16 * 1024);
-        }
+        const void *fn = logits_out ? (const void *)vnet16_coop_kernel<true> : (const void *)vnet16_coop_kernel<false>;
+        if (int e = ensure_dynamic_lds(fn, (size_t)(kCoopMaxT / 16 * 1024))) return e;
         if (logits_out)
             hipLaunchKernelGGL((vnet16_coop_kernel<true>), dim3((unsigned)B), dim3(64 * kCoopWaves), dyn, st, y, y_ld, W1, b1, W2, b2, W3,
                                b3, dec, dec_ld, logits_out, final_metric, B, T, tx, tx_ld, K, row_mask, counters);
@@ -585,14 +624,8 @@ int launch_vnet16_fused(const float *y, int64_t y_ld, const float *W1, const flo
     return (int)hipGetLastError();
 }
 
-// The MVN_* switches (A/B runs, cross-checks in the tests).  Read through getenv on every call so that a test can flip them
-// between two calls; a getenv of an unset name is a ~20 ns scan of the environment block.
-bool env_is(const char *name, char c) {
-    const char *e = getenv(name);
-    return e && e[0] == c;
-}
 // MVN_GENERIC_SWEEP=1 forces the generic state-per-lane LDS sweep for every S (testing).
-bool generic_sweep_forced() { return env_is("MVN_GENERIC_SWEEP", '1'); }
+bool generic_sweep_forced() { return sw(SW_GENERIC_SWEEP) == '1'; }
 
 // Which kernel serves a sweep: ONE decision function used by the dispatcher and by the mvn_*_kernel_name queries, so the
 // name a caller is told is the kernel that runs (same environment switches, same alignment fall-backs).
@@ -605,11 +638,11 @@ SweepKind plan_sweep(const void *src, const void *dec, int64_t dec_ld, int64_t B
         // classical VA: the lane-bits x register-bits in-place kernel serves every S >= 4 except S = 16, which has its
         // own 16-blocks-per-wave / row kernels (MVN_VA_INPLACE=1 sends S = 16 there too, for cross-checks)
         // (and S = 256, one block per wave with scalar decisions; MVN_VA256=inplace keeps the family kernel there)
-        if (S == 256 && !generic && !env_is("MVN_VA256", 'i')) return SK_VA256_WAVE;
-        if (S >= 4 && !generic && (S != 16 || env_is("MVN_VA_INPLACE", '1'))) return SK_VA_INPLACE;
+        if (S == 256 && !generic && sw(SW_VA256) != 'i') return SK_VA256_WAVE;
+        if (S >= 4 && !generic && (S != 16 || sw(SW_VA_INPLACE) == '1')) return SK_VA_INPLACE;
         if (S == 16 && !generic) {  // MVN_VA16 = "rows" | "quad" | "tile" pins a variant (A/B, tests); default by size:
-            const char *e = getenv("MVN_VA16");  // one wave per block below 6 000 blocks, 16 blocks per wave from there on
-            if (e && (e[0] == 'r' || e[0] == 'q' || e[0] == 't')) return e[0] == 'q' ? SK_VA16_QUAD : e[0] == 't' ? SK_VA16_TILE : SK_S16_ROWS;
+            const char e = sw(SW_VA16);  // one wave per block below 6 000 blocks, 16 blocks per wave from there on
+            if (e == 'r' || e == 'q' || e == 't') return e == 'q' ? SK_VA16_QUAD : e == 't' ? SK_VA16_TILE : SK_S16_ROWS;
             return B >= kVaQuadMinBlocks ? SK_VA16_QUAD : SK_VA16_TILE;
         }
         return SK_GENERIC;
@@ -617,11 +650,11 @@ SweepKind plan_sweep(const void *src, const void *dec, int64_t dec_ld, int64_t B
         // materialised costs: the LDS-DMA kernels move 16-byte pieces and store float4 decisions; buffers that are not
         // 16-byte aligned take the row kernel (S = 16) or the generic kernel
         const bool aligned = !((reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dec) & 15) || (dec_ld & 3));
-        if (S >= 4 && !generic && aligned && (S != 16 || env_is("MVN_SWEEP_INPLACE", '1'))) return SK_SWEEP_INPLACE;
+        if (S >= 4 && !generic && aligned && (S != 16 || sw(SW_SWEEP_INPLACE) == '1')) return SK_SWEEP_INPLACE;
         if (S == 16 && !generic) {
             if (reinterpret_cast<uintptr_t>(src) & 15) return SK_S16_ROWS;
-            const char *e = getenv("MVN_SWEEP16");  // "rows" | "lds" | "quad" pins a variant; default by size
-            const char v = (e && (e[0] == 'q' || e[0] == 'l' || e[0] == 'r')) ? e[0] : (sweep16_quad_preferred(B) ? 'q' : 'l');
+            const char e = sw(SW_SWEEP16);  // "rows" | "lds" | "quad" pins a variant; default by size
+            const char v = (e == 'q' || e == 'l' || e == 'r') ? e : (sweep16_quad_preferred(B) ? 'q' : 'l');
             return v == 'q' ? SK_S16_QUAD : v == 'l' ? SK_S16_LDS : SK_S16_ROWS;
         }
         return SK_GENERIC;
@@ -701,6 +734,141 @@ int current_device_cus() {
 }
 
 
+// ---- launchers of the training kernels: one trial by value (`many` NULL) or R trials from a device array ----------------
+// Workgroups per trial when a pass is spread over one workgroup per chunk (train_groups.inc); < 2 = the single-workgroup
+// kernels serve the shape (one chunk, or more than kTrainMaxGroups)
+int online_groups(int T) {
+    const int g = (T + kTrainChunk - 1) / kTrainChunk;
+    return g > kTrainMaxGroups ? 0 : g;
+}
+int maml_groups(int T, int W, int second_order) {
+    const long long n_sup = (long long)W * T;
+    const long long g = second_order ? (n_sup + kHvRows - 1) / kHvRows : (n_sup + kTrainChunk - 1) / kTrainChunk;
+    return g > kTrainMaxGroups ? 0 : (int)g;
+}
+// floats between the workspace regions of consecutive trials (GroupSync, slots, private moment copies; 256-byte multiple)
+size_t trial_workspace_floats(int S, int groups) {
+    return ((maml_groups_workspace_bytes(S, groups) + 255) & ~(size_t)255) / sizeof(float);
+}
+
+// zero the GroupSync at the head of each of `trials` workspace regions
+hipError_t clear_group_syncs(float *workspace, size_t stride_floats, int trials, hipStream_t st) {
+    if (trials == 1) return hipMemsetAsync(workspace, 0, sizeof(GroupSync), st);
+    return hipMemset2DAsync(workspace, stride_floats * sizeof(float), 0, sizeof(GroupSync), (size_t)trials, st);
+}
+
+template <class Launch>  // launch(SC tag): picks the instantiation for S
+int dispatch_states(int S, bool many, Launch launch) {
+    if (S == 16) return launch(std::integral_constant<int, 16>{});
+    if (S == 32 && !many) return launch(std::integral_constant<int, 32>{});  // (R trials at S = 32 take the run-time form)
+    return launch(std::integral_constant<int, 0>{});
+}
+
+int launch_online_train(const mvn_train_trial_t &one, const mvn_train_trial_t *many, int R, int T, int M, float lr, float beta1,
+                        float beta2, float eps, int S, void *workspace, size_t workspace_bytes, hipStream_t st) {
+    const size_t lds = online_train_lds_bytes(S);
+    const int lds_floats = (int)online_train_lds_floats(S);
+    int groups = M > 0 ? 0 : online_groups(T);  // minibatch iterations are one chunk: nothing to spread
+    const int cus = current_device_cus();
+    const size_t stride = groups >= 2 ? trial_workspace_floats(S, groups) : 0;
+    if (groups < 2 || !workspace || sw(SW_TRAIN_GROUPS) == '0' || groups > cus ||
+        workspace_bytes < (many ? (size_t)R * stride * sizeof(float) : train_groups_workspace_bytes(S, groups)))
+        groups = 0;
+    if (groups && (reinterpret_cast<uintptr_t>(workspace) & 15)) return MVN_E_WORKSPACE;
+    if (!groups) {  // one workgroup per trial
+        return dispatch_states(S, many != nullptr, [&](auto sc) -> int {
+            constexpr int SC = decltype(sc)::value;
+            if (many) {
+                if (int e = ensure_dynamic_lds((const void *)online_train_kernel<SC == 32 ? 0 : SC, true>, lds)) return e;
+                hipLaunchKernelGGL((online_train_kernel<SC == 32 ? 0 : SC, true>), dim3(1, (unsigned)R), dim3(kTrainThreads), lds, st,
+                                   one, many, T, M, lr, beta1, beta2, eps, S, lds_floats);
+            } else {
+                if (int e = ensure_dynamic_lds((const void *)online_train_kernel<SC, false>, lds)) return e;
+                hipLaunchKernelGGL((online_train_kernel<SC, false>), dim3(1), dim3(kTrainThreads), lds, st, one, many, T, M, lr,
+                                   beta1, beta2, eps, S, lds_floats);
+            }
+            return (int)hipGetLastError();
+        });
+    }
+    // one workgroup per chunk and trial, never more workgroups in a launch than the device has CUs (all resident at once)
+    const int per_launch = many ? std::max(1, cus / groups) : 1;
+    for (int r0 = 0; r0 < R; r0 += per_launch) {
+        const int nr = std::min(per_launch, R - r0);
+        float *wsr = (float *)workspace + (size_t)r0 * stride;
+        hipError_t e = clear_group_syncs(wsr, stride, nr, st);
+        if (e != hipSuccess) return (int)e;
+        const GroupLaunch gl = {wsr, (long long)stride, g_group_spin_limit, g_group_phantoms};
+        const int rc = dispatch_states(S, many != nullptr, [&](auto sc) -> int {
+            constexpr int SC = decltype(sc)::value;
+            if (many) {
+                if (int e2 = ensure_dynamic_lds((const void *)online_train_groups_kernel<SC == 32 ? 0 : SC, true>, lds)) return e2;
+                hipLaunchKernelGGL((online_train_groups_kernel<SC == 32 ? 0 : SC, true>), dim3((unsigned)groups, (unsigned)nr),
+                                   dim3(kTrainThreads), lds, st, one, many + r0, T, lr, beta1, beta2, eps, S, lds_floats, gl);
+            } else {
+                if (int e2 = ensure_dynamic_lds((const void *)online_train_groups_kernel<SC, false>, lds)) return e2;
+                hipLaunchKernelGGL((online_train_groups_kernel<SC, false>), dim3((unsigned)groups), dim3(kTrainThreads), lds, st, one,
+                                   many, T, lr, beta1, beta2, eps, S, lds_floats, gl);
+            }
+            return (int)hipGetLastError();
+        });
+        if (rc) return rc;
+    }
+    return MVN_OK;
+}
+
+int launch_maml_train(const mvn_train_trial_t &one, const mvn_train_trial_t *many, int R, int T, int W, float meta_lr,
+                      int second_order, float lr, float beta1, float beta2, float eps, int S, void *workspace,
+                      size_t workspace_bytes, hipStream_t st) {
+    const size_t lds = maml_train_lds_floats(S) * sizeof(float);
+    const int lds_floats = (int)maml_train_lds_floats(S);
+    int groups = maml_groups(T, W, second_order);  // one workgroup per chunk of the largest pass
+    const int cus = current_device_cus();
+    const size_t stride = groups >= 2 ? trial_workspace_floats(S, groups) : 0;
+    if (groups < 2 || !workspace || sw(SW_TRAIN_GROUPS) == '0' || groups > cus ||
+        workspace_bytes < (many ? (size_t)R * stride * sizeof(float) : maml_groups_workspace_bytes(S, groups)))
+        groups = 0;
+    if (groups && (reinterpret_cast<uintptr_t>(workspace) & 15)) return MVN_E_WORKSPACE;
+    if (!groups) {
+        return dispatch_states(S, many != nullptr, [&](auto sc) -> int {
+            constexpr int SC = decltype(sc)::value;
+            if (many) {
+                if (int e = ensure_dynamic_lds((const void *)maml_train_kernel<SC == 32 ? 0 : SC, true>, lds)) return e;
+                hipLaunchKernelGGL((maml_train_kernel<SC == 32 ? 0 : SC, true>), dim3(1, (unsigned)R), dim3(kTrainThreads), lds, st, one,
+                                   many, T, W, meta_lr, second_order, lr, beta1, beta2, eps, S, lds_floats);
+            } else {
+                if (int e = ensure_dynamic_lds((const void *)maml_train_kernel<SC, false>, lds)) return e;
+                hipLaunchKernelGGL((maml_train_kernel<SC, false>), dim3(1), dim3(kTrainThreads), lds, st, one, many, T, W, meta_lr,
+                                   second_order, lr, beta1, beta2, eps, S, lds_floats);
+            }
+            return (int)hipGetLastError();
+        });
+    }
+    const int per_launch = many ? std::max(1, cus / groups) : 1;
+    for (int r0 = 0; r0 < R; r0 += per_launch) {
+        const int nr = std::min(per_launch, R - r0);
+        float *wsr = (float *)workspace + (size_t)r0 * stride;
+        hipError_t e = clear_group_syncs(wsr, stride, nr, st);
+        if (e != hipSuccess) return (int)e;
+        const GroupLaunch gl = {wsr, (long long)stride, g_group_spin_limit, g_group_phantoms};
+        const int rc = dispatch_states(S, many != nullptr, [&](auto sc) -> int {
+            constexpr int SC = decltype(sc)::value;
+            if (many) {
+                if (int e2 = ensure_dynamic_lds((const void *)maml_train_groups_kernel<SC == 32 ? 0 : SC, true>, lds)) return e2;
+                hipLaunchKernelGGL((maml_train_groups_kernel<SC == 32 ? 0 : SC, true>), dim3((unsigned)groups, (unsigned)nr),
+                                   dim3(kTrainThreads), lds, st, one, many + r0, T, W, meta_lr, second_order, lr, beta1, beta2, eps, S,
+                                   lds_floats, gl);
+            } else {
+                if (int e2 = ensure_dynamic_lds((const void *)maml_train_groups_kernel<SC, false>, lds)) return e2;
+                hipLaunchKernelGGL((maml_train_groups_kernel<SC, false>), dim3((unsigned)groups), dim3(kTrainThreads), lds, st, one,
+                                   many, T, W, meta_lr, second_order, lr, beta1, beta2, eps, S, lds_floats, gl);
+            }
+            return (int)hipGetLastError();
+        });
+        if (rc) return rc;
+    }
+    return MVN_OK;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -719,6 +887,7 @@ const char *mvn_strerror(int code) {
         case MVN_E_NULL: return "mvn: required pointer is NULL";
         case MVN_E_WORKSPACE: return "mvn: workspace smaller than one block of logits";
         case MVN_E_DEVICE: return "mvn: current HIP device is not gfx950";
+        case MVN_E_BARRIER: return "mvn: a training launch abandoned its device-wide barrier (workgroups not co-resident); weights are NaN";
         default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
@@ -879,29 +1048,8 @@ int mvn_vnet_online_train_f32(const float *y, const int32_t *labels, int32_t T, 
                               int32_t n_iter, float *W1, float *b1, float *W2, float *b2, float *W3, float *b3,
                               float *adam_m, float *adam_v, int64_t step0, float lr, float beta1, float beta2, float eps,
                               float *loss_out, int32_t S, mvn_stream_t stream) {
-    if (T < 1 || n_iter < 0 || step0 < 0 || (batch_idx && M < 1)) return MVN_E_DIMS;
-    if (!valid_states(S) || S > 32) return MVN_E_STATES;  // parameters + Adam moments must fit the 160-KB LDS
-    if (n_iter == 0) return MVN_OK;
-    if (!y || !labels || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !adam_m || !adam_v) return MVN_E_NULL;
-    const size_t lds = online_train_lds_bytes(S);
-    static size_t lds_allowed[3] = {0, 0, 0};  // the opt-in to > 64 KB of dynamic LDS is per function: raise it when needed
-#define MVN_ONLINE_LAUNCH(SC, SLOT)                                                                                        \
-    do {                                                                                                                   \
-        if (lds > lds_allowed[SLOT]) {                                                                                     \
-            hipError_t e = hipFuncSetAttribute((const void *)online_train_kernel<SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return (int)e;                                                                            \
-            lds_allowed[SLOT] = lds;                                                                                       \
-        }                                                                                                                  \
-        hipLaunchKernelGGL(online_train_kernel<SC>, dim3(1), dim3(kTrainThreads), lds, (hipStream_t)stream, y, labels, T,   \
-                           batch_idx, M, n_iter, W1, b1, W2, b2, W3, b3, adam_m, adam_v, pow((double)beta1, (double)step0), \
-                           pow((double)beta2, (double)step0), lr, beta1, beta2, eps, loss_out, S,                           \
-                           (int)online_train_lds_floats(S));                                                               \
-    } while (0)
-    if (S == 16) MVN_ONLINE_LAUNCH(16, 0);
-    else if (S == 32) MVN_ONLINE_LAUNCH(32, 1);
-    else MVN_ONLINE_LAUNCH(0, 2);
-#undef MVN_ONLINE_LAUNCH
-    return (int)hipGetLastError();
+    return mvn_vnet_online_train_ws_f32(y, labels, T, batch_idx, M, n_iter, W1, b1, W2, b2, W3, b3, adam_m, adam_v, step0, lr,
+                                        beta1, beta2, eps, loss_out, S, nullptr, 0, nullptr, stream);
 }
 
 size_t mvn_vnet_train_workspace_bytes(int32_t S) {
@@ -909,40 +1057,50 @@ size_t mvn_vnet_train_workspace_bytes(int32_t S) {
     return maml_groups_workspace_bytes(S, kTrainMaxGroups);  // the larger of the two kernels' needs
 }
 
+size_t mvn_vnet_train_trials_workspace_bytes(int32_t S, int32_t T, int32_t W, int32_t R) {
+    if (!valid_states(S) || S > 32 || T < 1 || R < 1) return 0;
+    const int g = std::max(online_groups(T), std::max(maml_groups(T, W, 1), maml_groups(T, W, 0)));
+    return g < 2 ? 0 : (size_t)R * trial_workspace_floats(S, g) * sizeof(float);
+}
+
 int mvn_vnet_online_train_ws_f32(const float *y, const int32_t *labels, int32_t T, const int32_t *batch_idx, int32_t M,
                                  int32_t n_iter, float *W1, float *b1, float *W2, float *b2, float *W3, float *b3,
                                  float *adam_m, float *adam_v, int64_t step0, float lr, float beta1, float beta2, float eps,
-                                 float *loss_out, int32_t S, void *workspace, size_t workspace_bytes, mvn_stream_t stream) {
-    const int groups = T >= 1 ? (T + kTrainChunk - 1) / kTrainChunk : 0;
-    // one workgroup per 32-sample chunk of a full-word iteration; everything else is the single-workgroup kernel's job
-    if (batch_idx || groups < 2 || groups > kTrainMaxGroups || !workspace || !valid_states(S) || S > 32 || n_iter < 1 ||
-        workspace_bytes < train_groups_workspace_bytes(S, groups) || env_is("MVN_TRAIN_GROUPS", '0') || groups > current_device_cus())
-        return mvn_vnet_online_train_f32(y, labels, T, batch_idx, M, n_iter, W1, b1, W2, b2, W3, b3, adam_m, adam_v, step0, lr,
-                                         beta1, beta2, eps, loss_out, S, stream);
-    if (step0 < 0) return MVN_E_DIMS;
+                                 float *loss_out, int32_t S, void *workspace, size_t workspace_bytes, int32_t *status,
+                                 mvn_stream_t stream) {
+    if (T < 1 || n_iter < 0 || step0 < 0 || (batch_idx && M < 1)) return MVN_E_DIMS;
+    if (!valid_states(S) || S > 32) return MVN_E_STATES;  // parameters + Adam moments must fit the 160-KB LDS
+    if (n_iter == 0) return MVN_OK;
     if (!y || !labels || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !adam_m || !adam_v) return MVN_E_NULL;
-    if (reinterpret_cast<uintptr_t>(workspace) & 15) return MVN_E_WORKSPACE;
-    const size_t lds = online_train_lds_bytes(S);
-    static size_t lds_allowed[3] = {0, 0, 0};
-    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(GroupSync), (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
-#define MVN_ONLINE_GROUPS_LAUNCH(SC, SLOT)                                                                                  \
-    do {                                                                                                                   \
-        if (lds > lds_allowed[SLOT]) {                                                                                     \
-            e = hipFuncSetAttribute((const void *)online_train_groups_kernel<SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return (int)e;                                                                            \
-            lds_allowed[SLOT] = lds;                                                                                       \
-        }                                                                                                                  \
-        hipLaunchKernelGGL(online_train_groups_kernel<SC>, dim3(groups), dim3(kTrainThreads), lds, (hipStream_t)stream, y,  \
-                           labels, T, n_iter, W1, b1, W2, b2, W3, b3, adam_m, adam_v, pow((double)beta1, (double)step0),    \
-                           pow((double)beta2, (double)step0), lr, beta1, beta2, eps, loss_out, S,                           \
-                           (int)online_train_lds_floats(S), (float *)workspace);                                           \
-    } while (0)
-    if (S == 16) MVN_ONLINE_GROUPS_LAUNCH(16, 0);
-    else if (S == 32) MVN_ONLINE_GROUPS_LAUNCH(32, 1);
-    else MVN_ONLINE_GROUPS_LAUNCH(0, 2);
-#undef MVN_ONLINE_GROUPS_LAUNCH
-    return (int)hipGetLastError();
+    mvn_train_trial_t d = {};
+    d.y = y;
+    d.labels = labels;
+    d.idx = batch_idx;
+    float *w[6] = {W1, b1, W2, b2, W3, b3};
+    for (int a = 0; a < 6; ++a) {
+        d.w_in[a] = w[a];
+        d.w_out[a] = w[a];
+    }
+    d.adam_m = adam_m;
+    d.adam_v = adam_v;
+    d.loss_out = loss_out;
+    d.status = status;
+    d.b1pow = pow((double)beta1, (double)step0);
+    d.b2pow = pow((double)beta2, (double)step0);
+    d.n = n_iter;
+    return launch_online_train(d, nullptr, 1, T, batch_idx ? M : 0, lr, beta1, beta2, eps, S, workspace, workspace_bytes,
+                               (hipStream_t)stream);
+}
+
+int mvn_vnet_online_train_trials_f32(const mvn_train_trial_t *trials, int32_t R, int32_t T, int32_t M, float lr, float beta1,
+                                     float beta2, float eps, int32_t S, void *workspace, size_t workspace_bytes,
+                                     mvn_stream_t stream) {
+    if (T < 1 || R < 0 || M < 0) return MVN_E_DIMS;
+    if (!valid_states(S) || S > 32) return MVN_E_STATES;
+    if (R == 0) return MVN_OK;
+    if (!trials) return MVN_E_NULL;
+    return launch_online_train(mvn_train_trial_t{}, trials, R, T, M, lr, beta1, beta2, eps, S, workspace, workspace_bytes,
+                               (hipStream_t)stream);
 }
 
 int mvn_vnet_maml_train_f32(const float *rx_words, const int32_t *labels, int32_t T, const int32_t *support_idx, int32_t W,
@@ -950,70 +1108,91 @@ int mvn_vnet_maml_train_f32(const float *rx_words, const int32_t *labels, int32_
                             float *W3, float *b3, float *adam_m, float *adam_v, int64_t step0, float meta_lr,
                             int32_t second_order, float lr, float beta1, float beta2, float eps, float *loss_out, int32_t S,
                             mvn_stream_t stream) {
-    if (T < 1 || W < 1 || n_steps < 0 || step0 < 0) return MVN_E_DIMS;
-    if (!valid_states(S) || S > 32) return MVN_E_STATES;  // four parameter-sized vectors + a chunk must fit the 160-KB LDS
-    if (n_steps == 0) return MVN_OK;
-    if (!rx_words || !labels || !support_idx || !query_idx || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !adam_m || !adam_v)
-        return MVN_E_NULL;
-    const size_t lds = maml_train_lds_floats(S) * sizeof(float);
-    static size_t lds_allowed[3] = {0, 0, 0};
-#define MVN_MAML_LAUNCH(SC, SLOT)                                                                                          \
-    do {                                                                                                                   \
-        if (lds > lds_allowed[SLOT]) {                                                                                     \
-            hipError_t e = hipFuncSetAttribute((const void *)maml_train_kernel<SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return (int)e;                                                                            \
-            lds_allowed[SLOT] = lds;                                                                                       \
-        }                                                                                                                  \
-        hipLaunchKernelGGL(maml_train_kernel<SC>, dim3(1), dim3(kTrainThreads), lds, (hipStream_t)stream, rx_words, labels, T, \
-                           support_idx, W, query_idx, n_steps, W1, b1, W2, b2, W3, b3, adam_m, adam_v,                     \
-                           pow((double)beta1, (double)step0), pow((double)beta2, (double)step0), meta_lr, second_order, lr, \
-                           beta1, beta2, eps, loss_out, S, (int)maml_train_lds_floats(S));                                 \
-    } while (0)
-    if (S == 16) MVN_MAML_LAUNCH(16, 0);
-    else if (S == 32) MVN_MAML_LAUNCH(32, 1);
-    else MVN_MAML_LAUNCH(0, 2);
-#undef MVN_MAML_LAUNCH
-    return (int)hipGetLastError();
+    return mvn_vnet_maml_train_ws_f32(rx_words, labels, T, support_idx, W, query_idx, n_steps, W1, b1, W2, b2, W3, b3, adam_m,
+                                      adam_v, step0, meta_lr, second_order, lr, beta1, beta2, eps, loss_out, S, nullptr, 0,
+                                      nullptr, stream);
 }
 
 int mvn_vnet_maml_train_ws_f32(const float *rx_words, const int32_t *labels, int32_t T, const int32_t *support_idx, int32_t W,
                                const int32_t *query_idx, int32_t n_steps, float *W1, float *b1, float *W2, float *b2,
                                float *W3, float *b3, float *adam_m, float *adam_v, int64_t step0, float meta_lr,
                                int32_t second_order, float lr, float beta1, float beta2, float eps, float *loss_out, int32_t S,
-                               void *workspace, size_t workspace_bytes, mvn_stream_t stream) {
-    // one workgroup per chunk of the largest pass: the Hessian pass's 16-sample chunks when second order
-    const long long n_sup = (long long)W * T;
-    const long long groups_ll = (T >= 1 && W >= 1) ? (second_order ? (n_sup + kHvRows - 1) / kHvRows : (n_sup + kTrainChunk - 1) / kTrainChunk) : 0;
-    const int groups = groups_ll > kTrainMaxGroups ? 0 : (int)groups_ll;
-    if (groups < 2 || !workspace || !valid_states(S) || S > 32 || n_steps < 1 ||
-        workspace_bytes < maml_groups_workspace_bytes(S, groups) || env_is("MVN_TRAIN_GROUPS", '0') || groups > current_device_cus())
-        return mvn_vnet_maml_train_f32(rx_words, labels, T, support_idx, W, query_idx, n_steps, W1, b1, W2, b2, W3, b3, adam_m,
-                                       adam_v, step0, meta_lr, second_order, lr, beta1, beta2, eps, loss_out, S, stream);
-    if (step0 < 0) return MVN_E_DIMS;
+                               void *workspace, size_t workspace_bytes, int32_t *status, mvn_stream_t stream) {
+    if (T < 1 || W < 1 || n_steps < 0 || step0 < 0) return MVN_E_DIMS;
+    if (!valid_states(S) || S > 32) return MVN_E_STATES;  // four parameter-sized vectors + a chunk must fit the 160-KB LDS
+    if (n_steps == 0) return MVN_OK;
     if (!rx_words || !labels || !support_idx || !query_idx || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !adam_m || !adam_v)
         return MVN_E_NULL;
-    if (reinterpret_cast<uintptr_t>(workspace) & 15) return MVN_E_WORKSPACE;
-    const size_t lds = maml_train_lds_floats(S) * sizeof(float);
-    static size_t lds_allowed[3] = {0, 0, 0};
-    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(GroupSync), (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
-#define MVN_MAML_GROUPS_LAUNCH(SC, SLOT)                                                                                   \
-    do {                                                                                                                   \
-        if (lds > lds_allowed[SLOT]) {                                                                                     \
-            e = hipFuncSetAttribute((const void *)maml_train_groups_kernel<SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return (int)e;                                                                            \
-            lds_allowed[SLOT] = lds;                                                                                       \
-        }                                                                                                                  \
-        hipLaunchKernelGGL(maml_train_groups_kernel<SC>, dim3(groups), dim3(kTrainThreads), lds, (hipStream_t)stream,       \
-                           rx_words, labels, T, support_idx, W, query_idx, n_steps, W1, b1, W2, b2, W3, b3, adam_m, adam_v, \
-                           pow((double)beta1, (double)step0), pow((double)beta2, (double)step0), meta_lr, second_order, lr, \
-                           beta1, beta2, eps, loss_out, S, (int)maml_train_lds_floats(S), (float *)workspace);             \
+    mvn_train_trial_t d = {};
+    d.y = rx_words;
+    d.labels = labels;
+    d.idx = support_idx;
+    d.query_idx = query_idx;
+    float *w[6] = {W1, b1, W2, b2, W3, b3};
+    for (int a = 0; a < 6; ++a) {
+        d.w_in[a] = w[a];
+        d.w_out[a] = w[a];
+    }
+    d.adam_m = adam_m;
+    d.adam_v = adam_v;
+    d.loss_out = loss_out;
+    d.status = status;
+    d.b1pow = pow((double)beta1, (double)step0);
+    d.b2pow = pow((double)beta2, (double)step0);
+    d.n = n_steps;
+    return launch_maml_train(d, nullptr, 1, T, W, meta_lr, second_order, lr, beta1, beta2, eps, S, workspace, workspace_bytes,
+                             (hipStream_t)stream);
+}
+
+int mvn_vnet_maml_train_trials_f32(const mvn_train_trial_t *trials, int32_t R, int32_t T, int32_t W, float meta_lr,
+                                   int32_t second_order, float lr, float beta1, float beta2, float eps, int32_t S,
+                                   void *workspace, size_t workspace_bytes, mvn_stream_t stream) {
+    if (T < 1 || W < 1 || R < 0) return MVN_E_DIMS;
+    if (!valid_states(S) || S > 32) return MVN_E_STATES;
+    if (R == 0) return MVN_OK;
+    if (!trials) return MVN_E_NULL;
+    return launch_maml_train(mvn_train_trial_t{}, trials, R, T, W, meta_lr, second_order, lr, beta1, beta2, eps, S, workspace,
+                             workspace_bytes, (hipStream_t)stream);
+}
+
+int mvn_vnet_byword_step_f32(const float *rx, int64_t rx_ld, const float *tx, int64_t tx_ld, const float *W1, const float *b1,
+                             const float *W2, const float *b2, const float *W3, const float *b3, const int64_t *w_stride,
+                             float *dec, int64_t dec_ld, float *msg, int64_t msg_ld, float *enc, int64_t enc_ld,
+                             float *label_word, int64_t lw_ld, int32_t *labels, int64_t lab_ld, int32_t *nerr, int64_t R,
+                             int32_t T, int32_t nsym, int32_t pilot, int32_t S, mvn_stream_t stream) {
+    if (S != 16) return MVN_E_STATES;  // the fused step exists for the 16-state detector
+    if (R < 0 || T < 8 || (T & 7) || T > kCoopMaxT || nsym < 1 || nsym > 8 || T / 8 <= nsym) return MVN_E_DIMS;
+    const int K = T - 8 * nsym;
+    if (rx_ld < T || tx_ld < K || (dec && dec_ld < T) || (msg && msg_ld < K) || (enc && enc_ld < T) ||
+        (label_word && lw_ld < T) || (labels && lab_ld < T))
+        return MVN_E_DIMS;
+    if (R == 0) return MVN_OK;
+    if (!tx || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || (!pilot && !rx)) return MVN_E_NULL;
+    WeightStrides ws;
+    for (int a = 0; a < 6; ++a) ws.s[a] = w_stride ? (long long)w_stride[a] : 0;
+    const size_t dyn = pilot ? 0 : (size_t)((T + 15) / 16) * 1024;
+    hipStream_t st = (hipStream_t)stream;
+#define MVN_STEP_LAUNCH(NS)                                                                                              \
+    do {                                                                                                                \
+        int e = ensure_dynamic_lds((const void *)byword_step_kernel<NS>, (size_t)(kCoopMaxT / 16 * 1024));               \
+        if (e) return e;                                                                                                \
+        hipLaunchKernelGGL((byword_step_kernel<NS>), dim3((unsigned)R), dim3(64 * kCoopWaves), dyn, st, rx, rx_ld, tx,    \
+                           tx_ld, W1, b1, W2, b2, W3, b3, ws, dec, dec_ld, msg, msg_ld, enc, enc_ld, label_word, lw_ld,   \
+                           labels, lab_ld, nerr, T, nsym, pilot);                                                       \
     } while (0)
-    if (S == 16) MVN_MAML_GROUPS_LAUNCH(16, 0);
-    else if (S == 32) MVN_MAML_GROUPS_LAUNCH(32, 1);
-    else MVN_MAML_GROUPS_LAUNCH(0, 2);
-#undef MVN_MAML_GROUPS_LAUNCH
+    if (nsym <= 2) MVN_STEP_LAUNCH(2);
+    else MVN_STEP_LAUNCH(8);
+#undef MVN_STEP_LAUNCH
     return (int)hipGetLastError();
+}
+
+void mvn_reload_switches(void) { load_switches(); }
+
+/* test hooks (not part of include/mvn.h): spin limit of the training kernels' device-wide barrier, and phantom workgroups
+ * every barrier additionally waits for (> 0 forces the give-up path); negative arguments leave a setting unchanged */
+void mvn_test_hooks(int64_t group_spin_limit, int32_t group_phantoms) {
+    if (group_spin_limit >= 0) g_group_spin_limit = (unsigned)group_spin_limit;
+    if (group_phantoms >= 0) g_group_phantoms = group_phantoms;
 }
 
 int mvn_isi_awgn_transmit(const float *bits, int64_t ld_bits, int32_t K, const void *noise, int32_t noise_is_f64,

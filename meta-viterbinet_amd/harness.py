@@ -179,7 +179,7 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
                  MAML: bool = True, window_size: int = 1, meta_train_iterations: int = 20, meta_j_num: int = 10,
                  meta_subframes: int = 5, meta_style_online_training: bool = False,
                  graphed_meta: bool = True, hip_meta: bool = True, initial_buffer=None, weights_init: str = "last_frame",
-                 meta_training_weights=None) -> np.ndarray:
+                 meta_training_weights=None, draws=None, fused_step: bool = True) -> np.ndarray:
     """Sequential per-block online evaluation: counterpart of Trainer.eval_by_word (trainer.py:267-354).  Everything but the
     control flow stays on the GPU:
         for every block k:  detect (B=1)  ->  data block: RS decode, ser, RS re-encode | pilot: encode the known word
@@ -197,21 +197,37 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
     'meta_training' the weights in `meta_training_weights` (the reference loads its meta-trained checkpoint).
     tx [N, K] message bits, rx [N, K + 8*n_symbols] received words; block k is a pilot when k % subframes_in_frame == 0
     (trainer.py:100-102).  Returns ser_by_word [N] (0 for pilots), like the reference.
-    One host sync per block (the ser decides what happens next), as in the reference (trainer.py:305)."""
+    One host sync per block (the ser decides what happens next), as in the reference (trainer.py:305).
+    draws: a trials.TrialDraws -- the minibatches and j_hat values come from this trial's own streams instead of the global
+    generators (the reference's are unseeded), which is what makes a run replayable inside trials.eval_by_word_batched.
+    fused_step: a 16-state ViterbiNet detector with nsym <= 8 takes ONE launch per block (mvn_vnet_byword_step_f32:
+    detect, RS decode, error count, re-encode); False keeps the four separate launches (the cross-check in the tests)."""
     import copy
 
     from .meta import GraphedMetaStep, copy_model, meta_train_loop
 
     N = tx.shape[0]
     ser_by_word = np.zeros(N)
+    K = tx.shape[1]
+    fused = fused_step and _fused_step_applies(detector, rx, n_symbols, pass_count)
     if not (self_supervised or online_meta or verbose):
         # No update runs between blocks, so nothing on the host depends on a block's ser: the reference's 300 B=1 detector
-        # calls are issued exactly like it issues them, but the per-block ser stays on the device and ONE transfer ends the
-        # run (the reference synchronises after every block, trainer.py:305).
+        # calls are issued one by one like it issues them, but the per-block error counts stay on the device and ONE
+        # transfer ends the run (the reference synchronises after every block, trainer.py:305).  Pilot blocks are skipped:
+        # their ser is 0 and their detection only feeds the buffer of the update branches.
+        if fused:  # one launch per data block: detect + RS decode + error count (+ the re-encoding nobody reads here)
+            nerr = torch.zeros(N, dtype=torch.int32, device=rx.device)
+            for count in range(N):
+                if count % subframes_in_frame != 0:
+                    _byword_step(detector, rx[count:count + 1], tx[count:count + 1], n_symbols, False, nerr[count:count + 1])
+            e = nerr.cpu().numpy()
+            data = np.arange(N) % subframes_in_frame != 0
+            ser_by_word[data] = e[data].astype(np.float32) / np.float32(K)  # the reference's fp32 mean (metrics.py:13)
+            return ser_by_word
         counters = torch.zeros((N, 4), dtype=torch.int64, device=rx.device)  # row k: {bit errors, bits, ...} of block k
         for count in range(N):
             if count % subframes_in_frame == 0:
-                continue  # pilot block: ser 0, nothing to decode (its detection only feeds the buffer of the update branches)
+                continue
             received_word = rx[count:count + 1]
             detected_word = detector(received_word, "val", snr, gamma, count) if pass_count else detector(received_word, "val", snr, gamma)
             _metrics.count_errors(rs_decode(detected_word, n_symbols), tx[count:count + 1], None, counters[count])
@@ -241,17 +257,33 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
                 and online_trainer.optimizer_type == "Adam" and online_trainer.use_kernel)
     support_idx = torch.arange(-window_size - 1, -1, device=rx.device).long()  # :288
     query_idx = -1 * torch.ones(1, device=rx.device).long()
+
+    def draw_j_hat(high):  # trainer.py:337: the global generator, or this trial's own stream
+        if draws is None:
+            return torch.unique(torch.randint(low=0, high=high, size=[meta_j_num])).to(rx.device)
+        return torch.as_tensor(draws.j_hat(high, meta_j_num), device=rx.device).long()
+
+    nerr1 = torch.zeros(1, dtype=torch.int32, device=rx.device) if fused else None
     for count in range(N):
         transmitted_word, received_word = tx[count].reshape(1, -1), rx[count].reshape(1, -1)
-        detected_word = detector(received_word, "val", snr, gamma, count) if pass_count else detector(received_word, "val", snr, gamma)
-        if count % subframes_in_frame != 0:
-            decoded_word = rs_decode(detected_word, n_symbols)
-            ser = float((decoded_word != transmitted_word).float().mean().item())  # calculate_error_rates (:301)
-            encoded_word = rs_encode(decoded_word, n_symbols)  # :304
-            ser_by_word[count] = ser
+        pilot = count % subframes_in_frame == 0
+        if fused:  # ONE launch: detect, RS decode, error count, re-encode (pilot: encode the known word)
+            detected_word, encoded_word = _byword_step(detector, received_word, transmitted_word, n_symbols, pilot, nerr1)
+            ser = 0.0 if pilot else float(np.float32(int(nerr1.item())) / np.float32(K))  # calculate_error_rates (:301)
+            if not pilot:
+                ser_by_word[count] = ser
         else:
-            encoded_word = rs_encode(transmitted_word, n_symbols)  # pilot: the word is known (:314-316)
-            ser = 0.0
+            detected_word = detector(received_word, "val", snr, gamma, count) if pass_count else detector(received_word, "val", snr, gamma)
+            if not pilot:
+                decoded_word = rs_decode(detected_word, n_symbols)
+                ser = float((decoded_word != transmitted_word).float().mean().item())  # calculate_error_rates (:301)
+                encoded_word = rs_encode(decoded_word, n_symbols)  # :304
+                ser_by_word[count] = ser
+            else:
+                encoded_word = rs_encode(transmitted_word, n_symbols)  # pilot: the word is known (:314-316)
+                ser = 0.0
+        if online_trainer is not None:
+            online_trainer.check_status()  # a training launch that gave up its barrier (NaN weights) raises here
         if verbose:
             print(f"current: {count, ser}")
         if ser <= ser_thresh:  # :319-329 (buffer_empty=True: the buffer only grows)
@@ -274,7 +306,7 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
             if hip_meta:  # every MAML step of this update in ONE launch of the meta-learning kernel
                 sup, qry = [], []
                 for _ in range(meta_train_iterations):
-                    j_hat_values = torch.unique(torch.randint(low=0, high=buffer_rx.shape[0] - 2, size=[meta_j_num])).to(rx.device)
+                    j_hat_values = draw_j_hat(buffer_rx.shape[0] - 2)
                     sup.append(j_hat_values.reshape(-1, 1) + support_idx.reshape(1, -1) + 1)
                     qry.append(j_hat_values + query_idx + 1)
                 online_trainer.maml_training(buffer_rx, buffer_tx, torch.cat(sup), torch.cat(qry), meta_lr, MAML)
@@ -283,7 +315,7 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
                     meta_step = GraphedMetaStep(detector, meta_detector, online_trainer, window_size, rx.shape[1], meta_lr,
                                                 MAML)
                 for _ in range(meta_train_iterations):
-                    j_hat_values = torch.unique(torch.randint(low=0, high=buffer_rx.shape[0] - 2, size=[meta_j_num])).to(rx.device)
+                    j_hat_values = draw_j_hat(buffer_rx.shape[0] - 2)
                     for j_hat in j_hat_values:
                         if meta_step is not None:
                             meta_step(buffer_rx, buffer_tx, j_hat + support_idx + 1, j_hat + query_idx + 1)
@@ -294,6 +326,45 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
         if self_supervised and ser <= ser_thresh:  # :345-347
             if meta_style_online_training:
                 copy_model(source_model=saved_detector, dest_model=detector)  # metavnet_trainer.py:59
+            batch_idx = None
+            if draws is not None and not meta_style_online_training:
+                batch_idx = draws.batches(count, N, rx.shape[1], self_supervised_iterations, online_trainer.train_minibatch_size)
             online_trainer.online_training(buffer_tx[-1].reshape(1, -1), buffer_rx[-1].reshape(1, -1),
-                                           iterations=self_supervised_iterations, full_word=meta_style_online_training)
+                                           iterations=self_supervised_iterations, batch_idx=batch_idx,
+                                           full_word=meta_style_online_training)
+    if online_trainer is not None:
+        online_trainer.check_status()
     return ser_by_word
+
+
+def _fused_step_applies(detector, rx: torch.Tensor, n_symbols: int, pass_count: bool) -> bool:
+    """mvn_vnet_byword_step_f32 serves a 16-state VNETDetector whose 'val' length is the word length (Q5), words of whole
+    bytes up to 1024 symbols and nsym <= 8; everything else takes the separate detect / RS / count launches."""
+    from .detectors import VNETDetector
+
+    T = rx.shape[1]
+    return (isinstance(detector, VNETDetector) and detector.n_states == 16 and rx.is_cuda and not pass_count
+            and detector.transmission_lengths["val"] == T and T % 8 == 0 and 8 <= T <= 1024 and 1 <= n_symbols <= 8
+            and T // 8 > n_symbols)
+
+
+def _byword_step(detector, received_word: torch.Tensor, transmitted_word: torch.Tensor, n_symbols: int, pilot: bool,
+                 nerr: torch.Tensor):
+    """One block of eval_by_word in one launch (trainer.py:292-316): returns (detected_word, encoded_word) [1, T]; the
+    block's bit-error count goes to nerr[0] (device int32).  On a pilot the detection is skipped (never used) and
+    detected_word is None."""
+    from . import _lib
+
+    rxw, txw = _lib.f32c(received_word), _lib.f32c(transmitted_word)
+    T, K = rxw.shape[1], txw.shape[1]
+    dev = rxw.device
+    w = detector._params()
+    det = None if pilot else torch.empty((1, T), dtype=torch.float32, device=dev)
+    enc = torch.empty((1, T), dtype=torch.float32, device=dev)
+    with _lib.on_device(dev):
+        rc = _lib.load().mvn_vnet_byword_step_f32(_lib.ptr(rxw), T, _lib.ptr(txw), K, *[_lib.ptr(_lib.f32c(p)) for p in w], None,
+                                                  _lib.ptr(det), T, None, K, _lib.ptr(enc), T, None, T, None, T,
+                                                  _lib.ptr(nerr), 1, T, n_symbols, 1 if pilot else 0, 16,
+                                                  _lib.current_stream(dev))
+    _lib.check(rc, "mvn_vnet_byword_step_f32")
+    return det, enc

@@ -29,12 +29,26 @@ class OnlineTrainer:
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step = 0
+        # set to 1 by a training launch whose device-wide barrier gave up (include/mvn.h); read by check_status()
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev) if dev.type == "cuda" else None
+        self._unchecked = False
 
     def reset_state(self):
         """A fresh optimizer, like the deep_learning_setup() call of meta_weights_init('random') (trainer.py:356-359)."""
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
         self.step = 0
+
+    def check_status(self):
+        """Raises MvnError if a training launch since the last check abandoned its device-wide barrier (its weights are NaN):
+        the counterpart of the reference's NaN guard (trainer.py:496-498), which prints and skips the step.  Costs one
+        4-byte device-to-host copy, and only when a kernel launch is outstanding: call it where the host synchronises anyway
+        (harness.eval_by_word does after every block's `ser`)."""
+        if self._unchecked and self.status is not None:
+            self._unchecked = False
+            if int(self.status.item()) != 0:
+                self.status.zero_()
+                raise _lib.MvnError("OnlineTrainer: " + _lib.load().mvn_strerror(-7).decode())
 
     @torch.no_grad()
     def optimizer_step(self, grads):
@@ -120,8 +134,10 @@ class OnlineTrainer:
                                                         *[_lib.ptr(t.data) for t in p], _lib.ptr(self.exp_avg),
                                                         _lib.ptr(self.exp_avg_sq), self.step, meta_lr, 1 if MAML else 0,
                                                         self.lr, self.betas[0], self.betas[1], self.eps, _lib.ptr(loss),
-                                                        p[5].numel(), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev))
+                                                        p[5].numel(), _lib.ptr(ws), ws.numel(), _lib.ptr(self.status),
+                                                        _lib.current_stream(dev))
         _lib.check(rc, "mvn_vnet_maml_train_ws_f32")
+        self._unchecked = True
         self.step += n
         return loss
 
@@ -171,8 +187,9 @@ class OnlineTrainer:
                                                           *[_lib.ptr(t.data) for t in p], _lib.ptr(self.exp_avg),
                                                           _lib.ptr(self.exp_avg_sq), self.step, self.lr, self.betas[0],
                                                           self.betas[1], self.eps, _lib.ptr(loss), S, _lib.ptr(ws), ws.numel(),
-                                                          _lib.current_stream(dev))
+                                                          _lib.ptr(self.status), _lib.current_stream(dev))
         _lib.check(rc, "mvn_vnet_online_train_ws_f32")
+        self._unchecked = True
         self.step += iterations
         return loss
 

@@ -1,0 +1,280 @@
+"""R independent by-word evaluations advancing in lock-step on ONE GPU.
+
+Trainer.eval_by_word with online training between blocks (python_code/trainers/trainer.py:267-354) is sequential WITHIN a
+trial -- block k's weights depend on the blocks before it -- so it does not shard; the parallel axis is
+the (SNR x seed x method) grid the reference walks serially (plotters/plotter_main.py:117-149).  One trial occupies 1-9 of an
+MI355X's 256 CUs; here R trials step through their blocks together:
+
+    per block step:  ONE mvn_vnet_byword_step_f32 launch (detect + RS decode + error count + re-encode + labels for all R
+                     words, each with its own weights)  ->  ONE device-to-host copy of the R error counts (the only sync:
+                     every trial's next move depends on its coded ser, trainer.py:305,319)  ->  per-trial decisions on the
+                     host  ->  at most ONE mvn_vnet_maml_train_trials_f32 and ONE mvn_vnet_online_train_trials_f32 launch
+                     sequence for the trials that train (gridDim.y = trial, per-trial barrier counters).
+
+All per-trial state lives in stacked device tensors (TrialBank); the reference's buffer of (received word, label word) pairs
+is a list of block numbers per trial (the words themselves stay where the step kernel wrote them).  Per trial, the results --
+ser_by_word, final weights, Adam moments -- are bit-identical to harness.eval_by_word run alone with the same draws
+(tests/test_gpu_parity.py::test_batched_trials_equal_sequential_runs).
+"""
+import ctypes
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .detectors import HIDDEN1_SIZE, HIDDEN2_SIZE
+
+# include/mvn.h: mvn_train_trial_t
+TRIAL_DTYPE = np.dtype([("y", "u8"), ("labels", "u8"), ("idx", "u8"), ("query_idx", "u8"), ("w_in", "u8", (6,)),
+                        ("w_out", "u8", (6,)), ("w_out2", "u8", (6,)), ("adam_m", "u8"), ("adam_v", "u8"), ("loss_out", "u8"),
+                        ("status", "u8"), ("b1pow", "f8"), ("b2pow", "f8"), ("n", "i4"), ("reserved", "i4")])
+
+
+def param_offsets(n_states: int) -> np.ndarray:
+    """Offsets (floats) of W1, b1, W2, b2, W3, b3 in a flat parameter vector in parameters() order, and its length."""
+    sizes = [HIDDEN1_SIZE, HIDDEN1_SIZE, HIDDEN2_SIZE * HIDDEN1_SIZE, HIDDEN2_SIZE, n_states * HIDDEN2_SIZE, n_states]
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
+
+def beta_power(beta: float, step: int) -> float:
+    """(double)(float)beta ** step, exactly what the single-trial C entry points compute from (beta, step0)."""
+    return float(np.float32(beta)) ** int(step)
+
+
+class TrialDraws:
+    """The random draws of ONE trial's online training, a pure function of (seed, shapes): the minibatches of select_batch
+    (trainer.py:534-544: torch.multinomial with weights arange(T), without replacement) for every (block, iteration), drawn
+    in one call on the device when first needed, and the j_hat draws of the online meta-learning step (trainer.py:337:
+    torch.randint(0, len(buffer) - 2, [meta_j_num]), then unique) from a host generator.  The reference draws from the global
+    unseeded generators; giving every trial its own stream is what lets R trials run interleaved and still be replayed one
+    by one (harness.eval_by_word(draws=...)) with identical results."""
+
+    def __init__(self, seed: int, device):
+        self.seed = int(seed)
+        self.device = torch.device(device)
+        self.rng = np.random.RandomState(self.seed % (2 ** 32))
+        self._table = None
+        self._shape = None
+
+    def batches(self, count: int, n_blocks: int, T: int, iterations: int, M: int) -> torch.Tensor:
+        """int32 [iterations, M]: the minibatch indices of block `count` (a view into the trial's table)."""
+        shape = (n_blocks, T, iterations, M)
+        if self._table is None:
+            gen = torch.Generator(device=self.device).manual_seed(self.seed)
+            w = torch.arange(T, dtype=torch.float32, device=self.device).expand(n_blocks * iterations, T)
+            self._table = torch.multinomial(w, M, generator=gen).to(torch.int32).reshape(n_blocks, iterations, M)
+            self._shape = shape
+        elif self._shape != shape:
+            raise ValueError(f"TrialDraws was drawn for {self._shape}, asked for {shape}")
+        return self._table[count]
+
+    def j_hat(self, high: int, size: int) -> np.ndarray:
+        """np.unique(randint(0, high, size)): sorted distinct buffer positions, like torch.unique(torch.randint(...))."""
+        return np.unique(self.rng.randint(0, high, size=size))
+
+
+class TrialBank:
+    """Weights, saved weights (the reference's saved_detector, trainer.py:275) and Adam state of R ViterbiNet detectors in
+    stacked device tensors; row r is trial r, a row holds the six arrays flat in parameters() order."""
+
+    def __init__(self, weights: Sequence[Sequence], n_states: int, memory_length: int, device, lr: float = 0.001,
+                 betas=(0.9, 0.999), eps: float = 1e-8):
+        self.R = len(weights)
+        self.n_states, self.memory_length = n_states, memory_length
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.device = torch.device(device)
+        self.off = param_offsets(n_states)
+        self.P = int(self.off[-1])
+        rows = []
+        for w in weights:
+            if len(w) != 6:
+                raise ValueError("a trial's weights are six arrays in parameters() order")
+            rows.append(torch.cat([torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a.detach().cpu(), dtype=torch.float32).reshape(-1)
+                                   for a in w]))
+            if rows[-1].numel() != self.P:
+                raise ValueError(f"ViterbiNet parameter count {rows[-1].numel()} != {self.P}")
+        self.theta = torch.stack(rows).to(self.device).contiguous()
+        self.saved = self.theta.clone()
+        self.exp_avg = torch.zeros_like(self.theta)
+        self.exp_avg_sq = torch.zeros_like(self.theta)
+        self.step = np.zeros(self.R, dtype=np.int64)
+
+    def weights(self, r: int, saved: bool = False) -> List[torch.Tensor]:
+        """Trial r's six arrays as views with the shapes of VNETDetector.parameters()."""
+        row = (self.saved if saved else self.theta)[r]
+        shapes = [(HIDDEN1_SIZE, 1), (HIDDEN1_SIZE,), (HIDDEN2_SIZE, HIDDEN1_SIZE), (HIDDEN2_SIZE,), (self.n_states, HIDDEN2_SIZE),
+                  (self.n_states,)]
+        return [row[int(self.off[a]):int(self.off[a + 1])].reshape(s) for a, s in enumerate(shapes)]
+
+    def pointers(self, t: torch.Tensor) -> np.ndarray:
+        """uint64 [R, 6]: device addresses of the six arrays of every row of `t` (theta or saved)."""
+        base = np.uint64(t.data_ptr()) + np.arange(self.R, dtype=np.uint64)[:, None] * np.uint64(4 * self.P)
+        return base + (self.off[:6].astype(np.uint64) * np.uint64(4))[None, :]
+
+
+class _Staging:
+    """Pinned host image + device copy of per-step launch inputs (trial descriptors, index lists): filled on the host,
+    sent with one asynchronous copy.  The host image is only rewritten after the step's synchronisation, which follows
+    the copy on the same stream."""
+
+    def __init__(self, nbytes: int, device):
+        self.host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self.dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.np = self.host.numpy()
+
+    def send(self, nbytes: int):
+        self.dev[:nbytes].copy_(self.host[:nbytes], non_blocking=True)
+
+
+def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_symbols: int, subframes_in_frame: int,
+                         draws: Sequence[TrialDraws], self_supervised: bool = False, self_supervised_iterations: int = 200,
+                         ser_thresh: float = 0.02, online_meta: bool = False, meta_lr: float = 0.1, MAML: bool = True,
+                         window_size: int = 1, meta_train_iterations: int = 20, meta_j_num: int = 10, meta_subframes: int = 5,
+                         meta_style_online_training: bool = False, train_minibatch_size: int = 32,
+                         weights_init: str = "last_frame", meta_training_weights=None, record: Optional[dict] = None) -> np.ndarray:
+    """R trials of harness.eval_by_word (= Trainer.eval_by_word, trainer.py:267-354, buffer_empty=True, Adam) at once.
+    tx [R, N, K] message bits, rx [R, N, K + 8 n_symbols] received words (trial r = row r, its own SNR / channel / seed);
+    bank: the trials' weights and optimizer state (updated in place); draws[r]: trial r's TrialDraws.
+    Returns ser_by_word [R, N] (0 for pilots), row r equal to eval_by_word(..., draws=draws[r]) run alone.
+    record: optional dict that receives 'nerr' [R, N], 'trained' [R, N] bool and 'meta' [R, N] bool."""
+    if bank.n_states != 16:
+        raise NotImplementedError("the batched evaluation runs the 16-state kernels (mvn_vnet_byword_step_f32)")
+    if weights_init not in ("last_frame", "meta_training"):
+        raise NotImplementedError("weights_init='random' re-initialises one detector at a time: use harness.eval_by_word")
+    _lib.require_gpu_tensor(rx, "rx")
+    lib = _lib.load()
+    dev = rx.device
+    R, N, T = rx.shape
+    K = tx.shape[2]
+    if R != bank.R or len(draws) != R or tx.shape[0] != R or tx.shape[1] != N or K != T - 8 * n_symbols:
+        raise ValueError("tx [R, N, K], rx [R, N, K + 8 n_symbols], one TrialDraws and one bank row per trial")
+    rx = _lib.f32c(rx)
+    tx = _lib.f32c(tx).to(dev)
+    S, W = bank.n_states, window_size
+    b1, b2 = bank.betas
+    full_word = meta_style_online_training
+    M = 0 if full_word else train_minibatch_size
+
+    labels = torch.zeros((R, N, T), dtype=torch.int32, device=dev)  # calculate_states of every block's label word
+    sync_dev = torch.zeros(2 * R, dtype=torch.int32, device=dev)     # [0:R] bit errors of the step, [R:2R] training status
+    sync_host = torch.zeros(2 * R, dtype=torch.int32).pin_memory()
+    nerr_np, status_np = sync_host.numpy()[:R], sync_host.numpy()[R:]
+    ws_bytes = int(lib.mvn_vnet_train_trials_workspace_bytes(S, T, W, R))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    max_steps = meta_train_iterations * meta_j_num
+    desc = _Staging(2 * R * TRIAL_DTYPE.itemsize, dev)               # [0:R] meta-learning descriptors, [R:2R] online training
+    idx = _Staging(R * max_steps * (W + 1) * 4, dev) if online_meta else None
+    d_meta = desc.np[:R * TRIAL_DTYPE.itemsize].view(TRIAL_DTYPE)
+    d_onl = desc.np[R * TRIAL_DTYPE.itemsize:].view(TRIAL_DTYPE)
+    desc_meta_ptr = ctypes.c_void_p(desc.dev.data_ptr())
+    desc_onl_ptr = ctypes.c_void_p(desc.dev.data_ptr() + R * TRIAL_DTYPE.itemsize)
+    theta_p, saved_p = bank.pointers(bank.theta), bank.pointers(bank.saved)
+    m_p = np.uint64(bank.exp_avg.data_ptr()) + np.arange(R, dtype=np.uint64) * np.uint64(4 * bank.P)
+    v_p = np.uint64(bank.exp_avg_sq.data_ptr()) + np.arange(R, dtype=np.uint64) * np.uint64(4 * bank.P)
+    status_p = np.uint64(sync_dev.data_ptr()) + np.uint64(4) * (np.uint64(R) + np.arange(R, dtype=np.uint64))
+    rx_p = np.uint64(rx.data_ptr()) + np.arange(R, dtype=np.uint64) * np.uint64(4 * N * T)
+    lab_p = np.uint64(labels.data_ptr()) + np.arange(R, dtype=np.uint64) * np.uint64(4 * N * T)
+    if weights_init == "meta_training":
+        if meta_training_weights is None:
+            raise ValueError("weights_init='meta_training' needs meta_training_weights (six arrays in parameters() order)")
+        init_bank = TrialBank([meta_training_weights], S, bank.memory_length, dev)
+        init_p = np.repeat(init_bank.pointers(init_bank.theta), R, axis=0)
+    w_stride = (ctypes.c_int64 * 6)(*([bank.P] * 6))
+    wp = [ctypes.c_void_p(bank.theta.data_ptr() + 4 * int(bank.off[a])) for a in range(6)]
+    stream = _lib.current_stream(dev)
+    ts = torch.cuda.current_stream(dev)
+
+    ser_by_word = np.zeros((R, N))
+    buffers: List[List[int]] = [[] for _ in range(R)]  # trial r's buffer: the block numbers it holds, oldest first
+    if record is not None:
+        record.update(nerr=np.zeros((R, N), np.int64), trained=np.zeros((R, N), bool), meta=np.zeros((R, N), bool))
+    tables = None
+    with _lib.on_device(dev):
+        for count in range(N):
+            pilot = 1 if count % subframes_in_frame == 0 else 0
+            rc = lib.mvn_vnet_byword_step_f32(ctypes.c_void_p(rx.data_ptr() + 4 * count * T), N * T,
+                                              ctypes.c_void_p(tx.data_ptr() + 4 * count * K), N * K, *wp, w_stride,
+                                              None, T, None, K, None, T, None, T,
+                                              ctypes.c_void_p(labels.data_ptr() + 4 * count * T), N * T,
+                                              ctypes.c_void_p(sync_dev.data_ptr()), R, T, n_symbols, pilot, S, stream)
+            _lib.check(rc, "mvn_vnet_byword_step_f32")
+            sync_host.copy_(sync_dev, non_blocking=True)
+            ts.synchronize()  # the one host sync of the step (the reference has one per trial and block, trainer.py:305)
+            if status_np.any():
+                raise _lib.MvnError(f"trials {np.flatnonzero(status_np).tolist()}: {lib.mvn_strerror(-7).decode()}")
+            ser = (nerr_np.astype(np.float32) / np.float32(K)).astype(np.float64)  # the reference's fp32 mean (metrics.py:13)
+            if not pilot:
+                ser_by_word[:, count] = ser
+            push = ser <= ser_thresh  # trainer.py:319-324 (buffer_empty=True: the buffer only grows)
+            for r in np.flatnonzero(push):
+                buffers[r].append(count)
+            if record is not None:
+                record["nerr"][:, count] = nerr_np
+            # ---- online meta-learning (trainer.py:331-343): restart from the saved weights, all steps in one launch
+            if online_meta and count % meta_subframes == 0 and count >= meta_subframes:
+                act = [r for r in range(R) if len(buffers[r]) > 2]
+                if act:
+                    words = idx.np.view(np.int32)
+                    pos = 0
+                    for k, r in enumerate(act):
+                        buf = np.asarray(buffers[r], dtype=np.int64)
+                        sup, qry = [], []
+                        for _ in range(meta_train_iterations):
+                            j_hat = draws[r].j_hat(len(buf) - 2, meta_j_num)
+                            # support j_hat + [-W .. -1], query j_hat: positions in the buffer, negative = from its end
+                            sup.append(buf[(j_hat[:, None] + np.arange(-W, 0)[None, :]) % len(buf)])
+                            qry.append(buf[j_hat])
+                        sup, qry = np.concatenate(sup).astype(np.int32), np.concatenate(qry).astype(np.int32)
+                        n = qry.shape[0]
+                        words[pos:pos + n * W] = sup.reshape(-1)
+                        words[pos + n * W:pos + n * (W + 1)] = qry
+                        d = d_meta[k]
+                        d["y"], d["labels"] = rx_p[r], lab_p[r]
+                        d["idx"] = np.uint64(idx.dev.data_ptr() + 4 * pos)
+                        d["query_idx"] = np.uint64(idx.dev.data_ptr() + 4 * (pos + n * W))
+                        d["w_in"] = saved_p[r] if weights_init == "last_frame" else init_p[r]
+                        d["w_out"], d["w_out2"] = theta_p[r], saved_p[r]
+                        d["adam_m"], d["adam_v"], d["loss_out"], d["status"] = m_p[r], v_p[r], 0, status_p[r]
+                        d["b1pow"], d["b2pow"] = beta_power(b1, bank.step[r]), beta_power(b2, bank.step[r])
+                        d["n"], d["reserved"] = n, 0
+                        bank.step[r] += n
+                        pos += n * (W + 1)
+                        if record is not None:
+                            record["meta"][r, count] = True
+                    idx.send(4 * pos)
+                    desc.send(len(act) * TRIAL_DTYPE.itemsize)
+                    rc = lib.mvn_vnet_maml_train_trials_f32(desc_meta_ptr, len(act), T, W, meta_lr, 1 if MAML else 0, bank.lr,
+                                                            b1, b2, bank.eps, S, _lib.ptr(ws), ws_bytes, stream)
+                    _lib.check(rc, "mvn_vnet_maml_train_trials_f32")
+            # ---- self-supervised training on the word just buffered (trainer.py:345-347)
+            if self_supervised and push.any():
+                act = np.flatnonzero(push)
+                if M and tables is None:
+                    tables = [draws[r].batches(0, N, T, self_supervised_iterations, M) for r in range(R)]  # draws the tables
+                    tables = [draws[r]._table for r in range(R)]
+                for k, r in enumerate(act):
+                    d = d_onl[k]
+                    d["y"] = rx_p[r] + np.uint64(4 * count * T)
+                    d["labels"] = lab_p[r] + np.uint64(4 * count * T)
+                    d["idx"] = np.uint64(tables[r].data_ptr() + 4 * count * self_supervised_iterations * M) if M else 0
+                    d["query_idx"] = 0
+                    d["w_in"] = saved_p[r] if meta_style_online_training else theta_p[r]  # metavnet_trainer.py:59
+                    d["w_out"], d["w_out2"] = theta_p[r], 0
+                    d["adam_m"], d["adam_v"], d["loss_out"], d["status"] = m_p[r], v_p[r], 0, status_p[r]
+                    d["b1pow"], d["b2pow"] = beta_power(b1, bank.step[r]), beta_power(b2, bank.step[r])
+                    d["n"], d["reserved"] = self_supervised_iterations, 0
+                    bank.step[r] += self_supervised_iterations
+                    if record is not None:
+                        record["trained"][r, count] = True
+                off = R * TRIAL_DTYPE.itemsize
+                desc.dev[off:off + len(act) * TRIAL_DTYPE.itemsize].copy_(desc.host[off:off + len(act) * TRIAL_DTYPE.itemsize],
+                                                                          non_blocking=True)
+                rc = lib.mvn_vnet_online_train_trials_f32(desc_onl_ptr, len(act), T, M, bank.lr, b1, b2, bank.eps, S,
+                                                          _lib.ptr(ws), ws_bytes, stream)
+                _lib.check(rc, "mvn_vnet_online_train_trials_f32")
+        sync_host.copy_(sync_dev, non_blocking=True)
+        ts.synchronize()
+        if status_np.any():
+            raise _lib.MvnError(f"trials {np.flatnonzero(status_np).tolist()}: {lib.mvn_strerror(-7).decode()}")
+    return ser_by_word

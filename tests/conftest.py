@@ -25,6 +25,35 @@ def pytest_sessionstart(session):
         ge.build_hip()
 
 
+def _reload_switches():
+    """libmvn_hip.so reads its MVN_* switches once per process; tell it when a test has changed them."""
+    mvn = sys.modules.get("meta_viterbinet_amd")
+    if mvn is not None and mvn._lib._lib is not None:
+        mvn._lib._lib.mvn_reload_switches()
+
+
+@pytest.fixture(autouse=True)
+def _mvn_switches(monkeypatch):
+    """Every monkeypatch.setenv / delenv of an MVN_* switch takes effect at once (the library re-reads its switches), and
+    a test starts from the environment as it is (whatever the previous test's teardown restored)."""
+    _reload_switches()
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv_reload(name, value, *a, **k):
+        setenv(name, value, *a, **k)
+        if name.startswith("MVN_"):
+            _reload_switches()
+
+    def delenv_reload(name, *a, **k):
+        delenv(name, *a, **k)
+        if name.startswith("MVN_"):
+            _reload_switches()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv_reload, delenv_reload
+    yield
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

@@ -37,9 +37,9 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.mvn_version() == 3
+    assert lib.mvn_version() == 4
     assert lib.mvn_strerror(0) == b"ok"
-    for code in (-1, -2, -3, -4, -5, -6, -99):
+    for code in (-1, -2, -3, -4, -5, -6, -7, -99):
         assert lib.mvn_strerror(code).startswith(b"mvn:")
 
 
@@ -65,6 +65,45 @@ def test_argument_validation_needs_no_device(lib):
     assert lib.mvn_count_errors(None, 4, None, 4, None, 2, 4, None, None) == -4
     assert lib.mvn_vnet_workspace_bytes(10, 100, 4) == 10 * 100 * 4 * 4
     assert lib.mvn_vnet_workspace_bytes(10, 100, 16) == 0  # fused kernel: logits never leave the chip
+    # the by-word step: 16 states, whole bytes, nsym <= 8, a row stride for every output that is given
+    step = lambda T, nsym, S, R=1, rx_ld=None: lib.mvn_vnet_byword_step_f32(  # noqa: E731
+        None, T if rx_ld is None else rx_ld, None, T, *([None] * 6), None, None, T, None, T, None, T, None, T, None, T, None, R, T,
+        nsym, 0, S, None)
+    assert step(136, 2, 8) == -2 and step(136, 2, 256) == -2
+    assert step(135, 2, 16) == -1 and step(136, 9, 16) == -1 and step(16, 2, 16) == -1 and step(2048, 2, 16) == -1
+    assert step(136, 2, 16, rx_ld=100) == -1
+    assert step(136, 2, 16, R=0) == 0 and step(136, 2, 16) == -4
+    # trial-batched training: shapes before pointers; no trials = nothing to do; workspace sizes
+    assert lib.mvn_vnet_online_train_trials_f32(None, 4, 0, 0, 1e-3, 0.9, 0.999, 1e-8, 16, None, 0, None) == -1
+    assert lib.mvn_vnet_online_train_trials_f32(None, 4, 136, 0, 1e-3, 0.9, 0.999, 1e-8, 64, None, 0, None) == -2
+    assert lib.mvn_vnet_online_train_trials_f32(None, 0, 136, 0, 1e-3, 0.9, 0.999, 1e-8, 16, None, 0, None) == 0
+    assert lib.mvn_vnet_online_train_trials_f32(None, 4, 136, 0, 1e-3, 0.9, 0.999, 1e-8, 16, None, 0, None) == -4
+    assert lib.mvn_vnet_maml_train_trials_f32(None, 4, 136, 0, 0.1, 1, 1e-3, 0.9, 0.999, 1e-8, 16, None, 0, None) == -1
+    assert lib.mvn_vnet_maml_train_trials_f32(None, 4, 136, 1, 0.1, 1, 1e-3, 0.9, 0.999, 1e-8, 16, None, 0, None) == -4
+    one = lib.mvn_vnet_train_trials_workspace_bytes(16, 136, 1, 1)
+    assert one > 0 and one % 256 == 0 and lib.mvn_vnet_train_trials_workspace_bytes(16, 136, 1, 7) == 7 * one
+    assert lib.mvn_vnet_train_trials_workspace_bytes(16, 32, 1, 4) == lib.mvn_vnet_train_trials_workspace_bytes(16, 32, 1, 1) * 4
+    assert lib.mvn_vnet_train_trials_workspace_bytes(64, 136, 1, 4) == 0
+
+
+def test_trial_descriptor_layout_matches_the_header():
+    """trials.TRIAL_DTYPE is include/mvn.h's mvn_train_trial_t field for field (compiled here with the host compiler)."""
+    import subprocess
+    import tempfile
+
+    import meta_viterbinet_amd as mvn
+
+    fields = ["y", "labels", "idx", "query_idx", "w_in", "w_out", "w_out2", "adam_m", "adam_v", "loss_out", "status", "b1pow",
+              "b2pow", "n", "reserved"]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "mvn.h"\nint main(void){printf("%zu", sizeof(mvn_train_trial_t));' + "".join(
+        f'printf(" %zu", offsetof(mvn_train_trial_t, {f}));' for f in fields) + "return 0;}\n"
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")], check=True)
+        out = [int(v) for v in subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()]
+    dt = mvn.trials.TRIAL_DTYPE
+    assert out[0] == dt.itemsize
+    assert out[1:] == [dt.fields[f][1] for f in fields]
 
 
 def test_no_cpu_fallback_in_product_path():

@@ -1,0 +1,264 @@
+"""GPU tests (pytest -m gpu) of the by-word step kernel, of R evaluations advancing together on one GPU, and of the training
+kernels' failure reporting and behaviour under concurrency.  Bit-exact comparisons throughout: the batched forms run the
+same arithmetic as the sequential ones, which are pinned to the reference elsewhere (test_gpu_parity.py, G7-G11)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import meta_viterbinet_amd as mvn
+from meta_viterbinet_amd.trials import TrialBank, TrialDraws, eval_by_word_batched
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    assert mvn._lib.load().mvn_device_info(None, None, None, 0) == 0
+    return torch.device("cuda:0")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _vnet_with(w, T, dev):
+    det = mvn.VNETDetector(16, {"train": T, "val": T}).to(dev)
+    with torch.no_grad():
+        for p, a in zip(det.parameters(), w):
+            p.copy_(torch.as_tensor(a))
+    return det
+
+
+def _trial_weights(golden, R, seed=0, spread=0.05):
+    """R weight sets: the reference-trained weights of G7, each perturbed a little so that the trials differ."""
+    g7 = golden("g7_by_word")
+    rng = np.random.RandomState(seed)
+    base = [g7[f"w{i}"] for i in range(6)]
+    return [[(a * (1.0 + spread * rng.standard_normal(a.shape))).astype(np.float32) if r else a.astype(np.float32) for a in base]
+            for r in range(R)]
+
+
+def _words(dev, R, N, K, nsym, snrs, seed, L=4):
+    """tx [R, N, K] message bits and rx [R, N, K + 8 nsym]: trial r at snrs[r] over the fading time-decay channel."""
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    T = K + 8 * nsym
+    msg = torch.randint(0, 2, (R, N, K), generator=gen, device=dev).float()
+    cw = mvn.rs_encode(msg.reshape(R * N, K), nsym)
+    h = np.concatenate([mvn.estimate_channel(L, 0.2, "time_decay", fading=True, index=i, fading_taps_type=2) for i in range(N)])
+    rx = torch.stack([mvn.transmit(cw[r * N:(r + 1) * N], h, float(snrs[r]), L,
+                                   torch.randn(N, T, generator=gen, device=dev)) for r in range(R)])
+    return msg, rx.contiguous()
+
+
+def _step(dev, rx, tx, bank_theta, off, nsym, pilot, stride=True):
+    """mvn_vnet_byword_step_f32 with every output requested."""
+    R, T = rx.shape
+    K = T - 8 * nsym
+    out = dict(dec=torch.full((R, T), 7.0, device=dev), msg=torch.full((R, K), 7.0, device=dev), enc=torch.full((R, T), 7.0, device=dev),
+               lw=torch.full((R, T), 7.0, device=dev), labels=torch.full((R, T), -1, dtype=torch.int32, device=dev),
+               nerr=torch.full((R,), -1, dtype=torch.int32, device=dev))
+    P = bank_theta.shape[1]
+    wp = [ctypes.c_void_p(bank_theta.data_ptr() + 4 * int(off[a])) for a in range(6)]
+    ws = (ctypes.c_int64 * 6)(*([P] * 6)) if stride else None
+    rc = mvn._lib.load().mvn_vnet_byword_step_f32(mvn._lib.ptr(rx), T, mvn._lib.ptr(tx), K, *wp, ws, mvn._lib.ptr(out["dec"]), T,
+                                                  mvn._lib.ptr(out["msg"]), K, mvn._lib.ptr(out["enc"]), T, mvn._lib.ptr(out["lw"]), T,
+                                                  mvn._lib.ptr(out["labels"]), T, mvn._lib.ptr(out["nerr"]), R, T, nsym,
+                                                  1 if pilot else 0, 16, mvn._lib.current_stream(dev))
+    assert rc == 0
+    return out
+
+
+@pytest.mark.parametrize("R,K,nsym,snr", [(1, 120, 2, 10.0), (33, 120, 2, 6.0), (5, 120, 8, 4.0), (3, 984, 5, 9.0), (40, 8, 1, 3.0)])
+def test_byword_step_equals_the_separate_launches(golden, dev, R, K, nsym, snr):
+    """One launch = detect + RS decode + error count + RS encode + label word + trellis states, for R words with R weight
+    sets, against VNETDetector.forward('val'), mvn.rs_decode, a plain comparison, mvn.rs_encode and calculate_states run
+    word by word.  The SNRs are low enough that some words exceed the code's correction capacity (the reference's
+    uncorrected / mis-corrected outputs included), and one word is sent clean so that the no-error branch is taken too."""
+    T = K + 8 * nsym
+    w = _trial_weights(golden, R, seed=R + K)
+    bank = TrialBank(w, 16, 4, dev)
+    msg, rx = _words(dev, R, 1, K, nsym, [snr] * (R - 1) + [40.0], seed=7 * R + nsym)
+    msg, rx = msg[:, 0].contiguous(), rx[:, 0].contiguous()
+    out = _step(dev, rx, msg, bank.theta, bank.off, nsym, pilot=False)
+    n_err_words = 0
+    for r in range(R):
+        det = _vnet_with(w[r], T, dev)
+        dec = det(rx[r:r + 1], "val")
+        dmsg = mvn.rs_decode(dec, nsym)
+        enc = mvn.rs_encode(dmsg, nsym)
+        nerr = int((dmsg != msg[r:r + 1]).sum().item())
+        lw = dec if nerr > 0 else enc
+        assert torch.equal(out["dec"][r:r + 1], dec), r
+        assert torch.equal(out["msg"][r:r + 1], dmsg), r
+        assert torch.equal(out["enc"][r:r + 1], enc), r
+        assert int(out["nerr"][r].item()) == nerr, r
+        assert torch.equal(out["lw"][r:r + 1], lw), r
+        assert torch.equal(out["labels"][r].long(), mvn.calculate_states(4, lw)), r
+        n_err_words += nerr > 0
+    assert int(out["nerr"][R - 1].item()) == 0
+    if R > 1:
+        assert n_err_words > 0  # the detected-word branch of the label rule ran
+    # pilot step: the known word is encoded, nothing is detected (dec / msg untouched)
+    pil = _step(dev, rx, msg, bank.theta, bank.off, nsym, pilot=True)
+    enc = mvn.rs_encode(msg, nsym)
+    assert torch.equal(pil["enc"], enc) and torch.equal(pil["lw"], enc) and int(pil["nerr"].abs().sum().item()) == 0
+    assert torch.equal(pil["labels"].long().reshape(-1), mvn.calculate_states(4, enc))
+    assert bool((pil["dec"] == 7.0).all()) and bool((pil["msg"] == 7.0).all())
+    # one weight set for all words (w_stride NULL): every word decoded with trial 0's weights
+    shared = _step(dev, rx, msg, bank.theta, bank.off, nsym, pilot=False, stride=False)
+    assert torch.equal(shared["dec"], _vnet_with(w[0], T, dev)(rx, "val"))
+
+
+def test_eval_by_word_fused_step_equals_separate_launches(golden, dev):
+    """harness.eval_by_word with one launch per block against the four-launch route: the no-update loop of G7 (which is
+    also pinned to the reference's ser_by_word there) and a self-supervised run (same draws): identical ser and weights."""
+    g7 = golden("g7_by_word")
+    w = [g7[f"w{i}"] for i in range(6)]
+    msg, rx = _words(dev, 1, 100, 120, 2, [8.0], seed=21)
+    msg, rx = msg[0], rx[0]
+    a = mvn.eval_by_word(_vnet_with(w, 136, dev), msg, rx, 8.0, 0.2, 2, 25)
+    b = mvn.eval_by_word(_vnet_with(w, 136, dev), msg, rx, 8.0, 0.2, 2, 25, fused_step=False)
+    assert np.array_equal(a, b) and a.max() > 0
+    out = []
+    for fused in (True, False):
+        det = _vnet_with(w, 136, dev)
+        tr = mvn.OnlineTrainer(det, 4)
+        ser = mvn.eval_by_word(det, msg, rx, 8.0, 0.2, 2, 25, self_supervised=True, online_trainer=tr, self_supervised_iterations=20,
+                               draws=TrialDraws(5, dev), fused_step=fused)
+        out.append((ser, [p.detach().clone() for p in det.parameters()], tr.exp_avg.clone(), tr.step))
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][3] == out[1][3] > 0
+    for p, q in zip(out[0][1], out[1][1]):
+        assert torch.equal(p, q)
+    assert torch.equal(out[0][2], out[1][2])
+
+
+FLOWS = {
+    # BASELINE configs[2] with updates: 32-sample minibatch iterations after every qualifying block (vnet_trainer.py:49-60)
+    "self_supervised_minibatch": dict(self_supervised=True, self_supervised_iterations=25),
+    # BASELINE configs[4]: meta-learning every 5 blocks + full-word iterations from the saved weights (metavnet_trainer.py:52-64)
+    "meta_viterbinet": dict(self_supervised=True, self_supervised_iterations=12, online_meta=True, meta_train_iterations=3,
+                            meta_j_num=4, meta_subframes=5, meta_style_online_training=True),
+    "meta_first_order_window2": dict(self_supervised=False, online_meta=True, MAML=False, window_size=2, meta_train_iterations=2,
+                                     meta_j_num=3, meta_subframes=5),
+}
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("flow", sorted(FLOWS))
+def test_batched_trials_equal_sequential_runs(golden, dev, flow):
+    """R trials stepping together (trials.eval_by_word_batched: one step launch, one sync, one launch sequence per training
+    kind and block for ALL trials) against the same trials run one after the other through harness.eval_by_word with the
+    same per-trial draws: ser_by_word, the final weights, the saved weights' effect, both Adam moments and the step counts
+    are IDENTICAL per trial.  Trials sit at different SNRs, so they push, train and meta-learn at different blocks."""
+    R, N, K, nsym, sub = 7, 58, 120, 2, 25
+    kw = FLOWS[flow]
+    snrs = [6.0, 7.0, 8.0, 9.0, 10.0, 11.0, 12.0]
+    w = _trial_weights(golden, R, seed=3)
+    msg, rx = _words(dev, R, N, K, nsym, snrs, seed=11)
+    bank = TrialBank(w, 16, 4, dev)
+    rec = {}
+    ser_b = eval_by_word_batched(bank, msg, rx, nsym, sub, [TrialDraws(100 + r, dev) for r in range(R)], record=rec, **kw)
+    trained_blocks = 0
+    for r in range(R):
+        det = _vnet_with(w[r], K + 8 * nsym, dev)
+        tr = mvn.OnlineTrainer(det, 4)
+        ser = mvn.eval_by_word(det, msg[r], rx[r], snrs[r], 0.2, nsym, sub, online_trainer=tr,
+                               meta_detector=mvn.META_VNETDetector(16, {"train": K + 8 * nsym, "val": K + 8 * nsym}),
+                               draws=TrialDraws(100 + r, dev), **kw)
+        assert np.array_equal(ser, ser_b[r]), (flow, r)
+        for a, b in zip(det.parameters(), bank.weights(r)):
+            assert torch.equal(a.detach(), b), (flow, r)
+        assert torch.equal(tr.exp_avg, bank.exp_avg[r]) and torch.equal(tr.exp_avg_sq, bank.exp_avg_sq[r]), (flow, r)
+        assert tr.step == int(bank.step[r]), (flow, r)
+        trained_blocks += int(rec["trained"][r].sum() + rec["meta"][r].sum())
+    assert trained_blocks > R  # the flows did train
+    assert len({tuple(row) for row in ser_b}) > 1  # and the trials are not copies of each other
+    if kw.get("self_supervised"):
+        per_trial = rec["trained"].sum(axis=1)
+        assert per_trial.min() < per_trial.max()  # different trials trained on different blocks
+
+
+def _hooks(spin_limit, phantoms):
+    fn = mvn._lib.load().mvn_test_hooks
+    fn.restype, fn.argtypes = None, [ctypes.c_int64, ctypes.c_int32]
+    fn(spin_limit, phantoms)
+
+
+def test_abandoned_group_barrier_is_reported_not_silent(golden, dev):
+    """A training launch whose device-wide barrier cannot complete (forced here: every barrier waits for one workgroup that
+    does not exist, with a short spin limit) must not hand back NaN weights with rc == 0 and nothing else: the status word
+    is set, OnlineTrainer.check_status() / harness.eval_by_word / trials.eval_by_word_batched raise MvnError."""
+    g7 = golden("g7_by_word")
+    w = [g7[f"w{i}"] for i in range(6)]
+    T = 136
+    gen = torch.Generator(device=dev).manual_seed(2)
+    y = torch.randn(1, T, generator=gen, device=dev)
+    tx = torch.randint(0, 2, (1, T), generator=gen, device=dev).float()
+    try:
+        _hooks(2000, 1)
+        det = _vnet_with(w, T, dev)
+        tr = mvn.OnlineTrainer(det, 4)
+        tr.online_training(tx, y, iterations=3, full_word=True)  # one workgroup per chunk: 5 workgroups, barrier of "6"
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(next(det.parameters())).all())
+        with pytest.raises(mvn._lib.MvnError, match="barrier"):
+            tr.check_status()
+        tr.check_status()  # reported once, then clear
+        det = _vnet_with(w, T, dev)
+        tr = mvn.OnlineTrainer(det, 4)
+        rxw = torch.randn(6, T, generator=gen, device=dev)
+        txw = torch.randint(0, 2, (6, T), generator=gen, device=dev).float()
+        tr.maml_training(rxw, txw, torch.tensor([[0], [1]], device=dev), torch.tensor([1, 2], device=dev), 0.1, True)
+        with pytest.raises(mvn._lib.MvnError, match="barrier"):
+            tr.check_status()
+        # the batched evaluation reads the trials' status words at its per-step sync
+        msg, rx = _words(dev, 3, 8, 120, 2, [12.0] * 3, seed=4)
+        bank = TrialBank([w] * 3, 16, 4, dev)
+        with pytest.raises(mvn._lib.MvnError, match="barrier"):
+            eval_by_word_batched(bank, msg, rx, 2, 25, [TrialDraws(r, dev) for r in range(3)], self_supervised=True,
+                                 self_supervised_iterations=2, meta_style_online_training=True)
+    finally:
+        _hooks(1 << 22, 0)
+    # and with the hook off the same calls succeed
+    det = _vnet_with(w, T, dev)
+    tr = mvn.OnlineTrainer(det, 4)
+    tr.online_training(tx, y, iterations=3, full_word=True)
+    tr.check_status()
+    assert bool(torch.isfinite(next(det.parameters())).all())
+
+
+def test_two_training_launches_in_flight(golden, dev):
+    """Two one-workgroup-per-chunk training calls in flight at once on two streams (each with its own workspace and barrier
+    counter; 5 + 9 workgroups on a 256-CU device): results identical to running them one after the other."""
+    g7 = golden("g7_by_word")
+    w = [g7[f"w{i}"] for i in range(6)]
+    T = 136
+    gen = torch.Generator(device=dev).manual_seed(6)
+    y = torch.randn(2, T, generator=gen, device=dev)
+    tx = torch.randint(0, 2, (2, T), generator=gen, device=dev).float()
+    rxw = torch.randn(6, T, generator=gen, device=dev)
+    txw = torch.randint(0, 2, (6, T), generator=gen, device=dev).float()
+    sup, qry = torch.arange(40, device=dev).reshape(-1, 1) % 6, (torch.arange(40, device=dev) + 1) % 6
+
+    def run(concurrent):
+        dets = [_vnet_with(w, T, dev) for _ in range(2)]
+        trs = [mvn.OnlineTrainer(d, 4) for d in dets]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)] if concurrent else [torch.cuda.current_stream(dev)] * 2
+        for rep in range(3):
+            with torch.cuda.stream(streams[0]):
+                trs[0].online_training(tx[:1], y[:1], iterations=150, full_word=True)
+            with torch.cuda.stream(streams[1]):
+                trs[1].maml_training(rxw, txw, sup, qry, 0.1, True)
+        torch.cuda.synchronize()
+        for t in trs:
+            t.check_status()
+        return [p.detach().clone() for d in dets for p in d.parameters()] + [t.exp_avg.clone() for t in trs]
+
+    serial, overlapped = run(False), run(True)
+    for a, b in zip(serial, overlapped):
+        assert torch.equal(a, b)
+    assert all(bool(torch.isfinite(a).all()) for a in serial)

@@ -48,6 +48,7 @@ for rnd in range(7):
     for c in combos:
         for (k, _), v in zip(axes, c):
             os.environ[k] = v
+        mvn._lib.reload_switches()
         run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

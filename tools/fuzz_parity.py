@@ -58,6 +58,7 @@ while time.time() < t_end:
     if rng.rand() < 0.3:
         os.environ["MVN_UNFUSED"] = "1"
     kind = str(rng.choice(["sweep", "va", "vnet"]))
+    mvn._lib.reload_switches()
     y = rng.normal(0, 1.5, (B, T)).astype(np.float32)
     if rng.rand() < 0.15:
         y[rng.randint(B), rng.randint(T)] = rng.choice([np.nan, np.inf, -np.inf])

@@ -30,6 +30,7 @@ for B in [int(a) for a in args] or [10000, 40000]:
             os.environ["MVN_SWEEP_INPLACE"] = "1"
         elif v:
             os.environ["MVN_SWEEP16"] = v
+        mvn._lib.reload_switches()
         dec = torch.zeros(B, T, device=dev)
 
         def run():

@@ -14,6 +14,7 @@ for S, B in cases:
     ref = None
     for variant in ("inplace", "generic"):
         os.environ["MVN_GENERIC_SWEEP"] = "1" if variant == "generic" else "0"
+        mvn._lib.reload_switches()
         dec = torch.zeros(B, T, device=dev)
         run = lambda: lib.mvn_acs_sweep_f32(mvn._lib.ptr(cost), mvn._lib.ptr(dec), T, None, B, T, S, st)
         for _ in range(3): run()

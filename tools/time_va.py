@@ -39,6 +39,7 @@ for L, B in cases:
             os.environ["MVN_VA_INPLACE"] = "1"
         elif variant == "generic":
             os.environ["MVN_GENERIC_SWEEP"] = "1"
+        mvn._lib.reload_switches()
         dec.zero_()
         for _ in range(3):
             run()
