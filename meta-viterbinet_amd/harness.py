@@ -222,7 +222,7 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
                     _byword_step(detector, rx[count:count + 1], tx[count:count + 1], n_symbols, False, nerr[count:count + 1])
             e = nerr.cpu().numpy()
             data = np.arange(N) % subframes_in_frame != 0
-            ser_by_word[data] = e[data].astype(np.float32) / np.float32(K)  # the reference's fp32 mean (metrics.py:13)
+            ser_by_word[data] = _metrics.ser_from_errors(e[data], K)  # the reference's value bit for bit (metrics.py:13-16)
             return ser_by_word
         counters = torch.zeros((N, 4), dtype=torch.int64, device=rx.device)  # row k: {bit errors, bits, ...} of block k
         for count in range(N):
@@ -233,7 +233,7 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
             _metrics.count_errors(rs_decode(detected_word, n_symbols), tx[count:count + 1], None, counters[count])
         c = counters.cpu().numpy()
         data = c[:, 1] > 0
-        ser_by_word[data] = (c[data, 0] / c[data, 1]).astype(np.float32)  # the reference's fp32 mean (metrics.py:13)
+        ser_by_word[data] = _metrics.ser_from_errors(c[data, 0], K)  # the reference's value bit for bit (metrics.py:13-16)
         return ser_by_word
     if (self_supervised or online_meta) and online_trainer is None:
         raise ValueError("self_supervised / online_meta need an OnlineTrainer (it owns the Adam state)")
@@ -269,14 +269,14 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
         pilot = count % subframes_in_frame == 0
         if fused:  # ONE launch: detect, RS decode, error count, re-encode (pilot: encode the known word)
             detected_word, encoded_word = _byword_step(detector, received_word, transmitted_word, n_symbols, pilot, nerr1)
-            ser = 0.0 if pilot else float(np.float32(int(nerr1.item())) / np.float32(K))  # calculate_error_rates (:301)
+            ser = 0.0 if pilot else float(_metrics.ser_from_errors(int(nerr1.item()), K))  # calculate_error_rates (:301)
             if not pilot:
                 ser_by_word[count] = ser
         else:
             detected_word = detector(received_word, "val", snr, gamma, count) if pass_count else detector(received_word, "val", snr, gamma)
             if not pilot:
                 decoded_word = rs_decode(detected_word, n_symbols)
-                ser = float((decoded_word != transmitted_word).float().mean().item())  # calculate_error_rates (:301)
+                ser = float(_metrics.ser_from_errors(int((decoded_word != transmitted_word).sum().item()), K))  # calculate_error_rates (:301)
                 encoded_word = rs_encode(decoded_word, n_symbols)  # :304
                 ser_by_word[count] = ser
             else:

@@ -31,6 +31,17 @@ def count_errors(prediction: torch.Tensor, target: torch.Tensor, rows: torch.Ten
     return counters
 
 
+def ser_from_errors(n_errors, n_bits: int):
+    """The reference's per-block ser from an error count, bit for bit: calculate_error_rates (metrics.py:11-16) takes the
+    fp32 mean of the `equal` mask -- (n_bits - n_errors) / n_bits rounded to fp32 -- and returns max(1 - that, 0) in Python
+    floats.  n_errors: int or integer array; returns float64 of the same shape (exactly the values the reference's
+    eval_by_word stores in ser_by_word, golden G7 / G9)."""
+    import numpy as np
+
+    acc = (np.float32(n_bits) - np.asarray(n_errors).astype(np.float32)) / np.float32(n_bits)
+    return np.maximum(1.0 - acc.astype(np.float64), 0.0)
+
+
 def rates_from_counters(counters) -> Tuple[float, float]:
     """(ser, fer) = (bit_errors/bits, frame_errors/frames) in float64.  The reference takes fp32 means
     (metrics.py:13,15): the two agree to ~1e-7 relative."""

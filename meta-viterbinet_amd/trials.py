@@ -24,6 +24,7 @@ import torch
 
 from . import _lib
 from .detectors import HIDDEN1_SIZE, HIDDEN2_SIZE
+from .metrics import ser_from_errors
 
 # include/mvn.h: mvn_train_trial_t
 TRIAL_DTYPE = np.dtype([("y", "u8"), ("labels", "u8"), ("idx", "u8"), ("query_idx", "u8"), ("w_in", "u8", (6,)),
@@ -203,7 +204,7 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
             ts.synchronize()  # the one host sync of the step (the reference has one per trial and block, trainer.py:305)
             if status_np.any():
                 raise _lib.MvnError(f"trials {np.flatnonzero(status_np).tolist()}: {lib.mvn_strerror(-7).decode()}")
-            ser = (nerr_np.astype(np.float32) / np.float32(K)).astype(np.float64)  # the reference's fp32 mean (metrics.py:13)
+            ser = ser_from_errors(nerr_np, K)  # the reference's value bit for bit (metrics.py:13-16)
             if not pilot:
                 ser_by_word[:, count] = ser
             push = ser <= ser_thresh  # trainer.py:319-324 (buffer_empty=True: the buffer only grows)

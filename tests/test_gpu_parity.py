@@ -545,9 +545,9 @@ def test_by_word_va_rs_end_to_end_gpu(golden, dev, coef):
     one_by_one = mvn.detect_by_word(det, y[:30], snr, 0.2, batched=False, pass_count=True)
     assert np.array_equal(_np(one_by_one), ref_det[:30])
     decoded = mvn.rs_decode(batched, nsym)
-    ser = (decoded != tx).float().mean(dim=1).cpu().numpy()
+    ser = mvn.metrics.ser_from_errors((decoded != tx).sum(dim=1).cpu().numpy(), tx.shape[1])
     data = g[f"{coef}_data_indices"]
-    assert np.allclose(ser[data], g[f"{coef}_ser_by_word"][data], rtol=1e-6, atol=1e-7)
+    assert np.array_equal(ser[data], g[f"{coef}_ser_by_word"][data])  # the reference's floats, bit for bit
     # aggregated coded evaluation (single_eval_at_point with use_ecc, trainer.py:232-239) over the data rows
     rows = torch.tensor(data, device=dev)
     s_c, f_c, c = mvn.single_eval_at_point(det, tx, y, snr, 0.2, rows, n_symbols=nsym)
@@ -686,7 +686,7 @@ def test_eval_by_word_loop_va_golden(golden, dev, coef):
     y = torch.tensor(g[f"{coef}_y"], device=dev)
     tx = torch.tensor(g[f"{coef}_tx"].astype(np.float32), device=dev)
     ser = mvn.eval_by_word(det, tx, y, snr, 0.2, nsym, sub, pass_count=True)
-    assert np.allclose(ser, g[f"{coef}_ser_by_word"], rtol=1e-6, atol=1e-7)
+    assert np.array_equal(ser, g[f"{coef}_ser_by_word"])  # the reference's floats, bit for bit
 
 
 def test_eval_by_word_self_supervised_tracks_channel(golden, dev):

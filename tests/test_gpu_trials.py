@@ -71,7 +71,7 @@ def _step(dev, rx, tx, bank_theta, off, nsym, pilot, stride=True):
     return out
 
 
-@pytest.mark.parametrize("R,K,nsym,snr", [(1, 120, 2, 10.0), (33, 120, 2, 6.0), (5, 120, 8, 4.0), (3, 984, 5, 9.0), (40, 8, 1, 3.0)])
+@pytest.mark.parametrize("R,K,nsym,snr", [(1, 120, 2, 10.0), (33, 120, 2, 6.0), (5, 120, 8, 4.0), (3, 984, 5, 5.0), (40, 8, 1, 3.0)])
 def test_byword_step_equals_the_separate_launches(golden, dev, R, K, nsym, snr):
     """One launch = detect + RS decode + error count + RS encode + label word + trellis states, for R words with R weight
     sets, against VNETDetector.forward('val'), mvn.rs_decode, a plain comparison, mvn.rs_encode and calculate_states run
@@ -98,7 +98,8 @@ def test_byword_step_equals_the_separate_launches(golden, dev, R, K, nsym, snr):
         assert torch.equal(out["lw"][r:r + 1], lw), r
         assert torch.equal(out["labels"][r].long(), mvn.calculate_states(4, lw)), r
         n_err_words += nerr > 0
-    assert int(out["nerr"][R - 1].item()) == 0
+    if nsym >= 2:  # (a lone parity byte corrects nothing, and symbol 0 of every word is decided 0: quirk Q1)
+        assert int(out["nerr"][R - 1].item()) == 0
     if R > 1:
         assert n_err_words > 0  # the detected-word branch of the label rule ran
     # pilot step: the known word is encoded, nothing is detected (dec / msg untouched)
