@@ -238,20 +238,66 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
     # (b) the reference's call pattern: 300 sequential B=1 calls, no update (rank 0)
     mvn.eval_by_word(det, msg[:5], rx[:5], SNR_DB, GAMMA, nsym, sub)
     ms2b, ser_seq = wall_ms(lambda: mvn.eval_by_word(det, msg, rx, SNR_DB, GAMMA, nsym, sub), dev)
-    kfused = kernel_name(lib.mvn_vnet_decode_kernel_name, 1, K + 8 * nsym, 16, 0)
+    kfused = "byword_step_kernel<2>"
 
-    # (c) self-supervised online training after every block: does not shard within a trial -> replicas (SNR x seed grid)
-    def trial_selfsup(i):
-        m_, r_ = words("cost2100", 7.0 + (i % 6), 100 + i)  # plotter_main.py:117-122: 7..12 dB
-        d_ = make_det()
-        return mvn.eval_by_word(d_, m_, r_, 7.0 + (i % 6), GAMMA, nsym, sub, self_supervised=True,
-                                online_trainer=mvn.OnlineTrainer(d_, L), self_supervised_iterations=200)
+    # (c) self-supervised online training after every block: does not shard within a trial -> replicas (SNR x seed grid),
+    # R trials per GPU advancing together (trials.eval_by_word_batched); one trial alone for comparison
+    from meta_viterbinet_amd.trials import TrialBank, TrialDraws, eval_by_word_batched
 
-    trial_selfsup(0)  # warm
-    ms2c, rep2 = wall_ms(lambda: mvn.replica_eval(trial_selfsup, world, rank=rank, world=world,
-                                                  device=dev if backend == "nccl" else "cpu"), dev)
-    ms2c = max_over_ranks(ms2c)
     T2 = K + 8 * nsym
+    w_np = [g7[f"w{i}"] for i in range(6)]
+    n_cu = ctypes.c_int()
+    lib.mvn_device_info(ctypes.byref(n_cu), None, None, 0)
+
+    def one_trial(coefficients, i, seed0, **kw):
+        m_, r_ = words(coefficients, 7.0 + (i % 6), seed0 + i)  # plotter_main.py:117-122: 7..12 dB
+        d_ = make_det()
+        return mvn.eval_by_word(d_, m_, r_, 7.0 + (i % 6), GAMMA, nsym, sub, online_trainer=mvn.OnlineTrainer(d_, L),
+                                meta_detector=mvn.META_VNETDetector(16, {"train": T2, "val": T2}), draws=TrialDraws(seed0 + i, dev), **kw)
+
+    def trial_batch(coefficients, seed0, stats, **kw):
+        def run(ids):
+            ws_ = [words(coefficients, 7.0 + (i % 6), seed0 + i) for i in ids]
+            bank = TrialBank([w_np] * len(ids), 16, L, dev)
+            draws = [TrialDraws(seed0 + i, dev) for i in ids]
+            if not kw.get("meta_style_online_training"):
+                for d_ in draws:  # the minibatch tables are inputs of the run, like the words
+                    d_.batches(0, N, T2, kw["self_supervised_iterations"], 32)
+            rec = {}
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            ser = eval_by_word_batched(bank, torch.stack([a for a, _ in ws_]), torch.stack([b for _, b in ws_]), nsym, sub, draws,
+                                       record=rec, **kw)
+            torch.cuda.synchronize(dev)
+            stats.update(ms=(time.perf_counter() - t0) * 1e3, trained=int(rec["trained"].sum()), meta=int(rec["meta"].sum()),
+                         adam_steps=int(bank.step.sum()))
+            return ser
+        return run
+
+    def training_roofline(stats, trials, iters, samples, maml, groups):
+        """Utilisation of the chip by the training launches: algorithmic MFMA FLOPs of all trials' training (35 kFLOP per
+        sample of a CrossEntropy forward + backward pass of the 6 066-parameter MLP; a second-order meta-learning step =
+        support + query gradient + a Hessian-vector pass of ~3 gradient passes over the support word) over the wall time of the
+        whole evaluation (detection, codec, host decisions included), against the f32 MFMA peak; cu_occupancy = CUs holding
+        a training workgroup while a training launch runs."""
+        online_steps = stats["trained"] * iters
+        maml_steps = stats["adam_steps"] - online_steps
+        flop = 35e3 * samples * online_steps + (35e3 * 2 * T2 + 105e3 * T2) * maml_steps
+        ach = flop / (stats["ms"] * 1e-3) / 1e12
+        per_launch = min(trials, max(1, n_cu.value // groups))
+        return {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "cu_occupancy": per_launch * groups / n_cu.value, "workgroups_per_trial": groups, "trials_per_launch": per_launch,
+                "adam_steps": stats["adam_steps"], "algorithmic_flop": flop}
+
+    R2 = int(os.environ.get("MVN_BENCH_TRIALS_SELFSUP", "128"))
+    kw2 = dict(self_supervised=True, self_supervised_iterations=200)
+    one_trial("cost2100", 0, 100, **kw2)  # warm
+    ms2c1, _ = wall_ms(lambda: one_trial("cost2100", 0, 100, **kw2), dev)
+    st2 = {}
+    run2 = trial_batch("cost2100", 100, st2, **kw2)
+    run2(list(range(rank, min(R2 * world, 4 * world), world)))  # warm
+    rep2 = mvn.replica_eval(run2, R2 * world, rank=rank, world=world, device=dev if backend == "nccl" else "cpu", batched=True)
+    ms2c = max_over_ranks(st2["ms"])
     out.append({"config": "BASELINE configs[2]: ViterbiNet L=4, COST2100 taps, 300-block evaluation by word (T=136, RS(17,15))",
                 "n_gpus": world, "kernel": kfused,
                 "joint_batched_block_sharded": {"ms": ms2a, "symbols_per_s": N * T2 / (ms2a * 1e-3), "coded_ser": ser2a,
@@ -259,32 +305,50 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
                                                         f"for all 300 blocks, rows sharded x{world}, one all-reduce of int64[4]"},
                 "joint_sequential_b1": {"ms": ms2b, "us_per_block": ms2b * 1e3 / N, "symbols_per_s": N * T2 / (ms2b * 1e-3),
                                         "mean_ser": float(np.mean(ser_seq)),
-                                        "what": "the reference's call pattern: 300 x {detect B=1, RS decode, ser, re-encode}"},
-                "self_supervised_replicas": {"ms": ms2c, "us_per_block": ms2c * 1e3 / N, "blocks_per_s": world * N / (ms2c * 1e-3),
-                                             "symbols_per_s": world * N * T2 / (ms2c * 1e-3), "mean_ser_by_trial": [float(v) for v in np.nanmean(rep2, axis=1)],
-                                             "what": f"200 CE+Adam iterations on the HIP training kernel after every block; {world} independent "
-                                                     "trial(s) (SNR 7..12 dB grid), one all_gather of ser_by_word[300]"},
+                                        "what": "the reference's sequential pattern without updates: per data block ONE launch of "
+                                                "byword_step_kernel (detect B=1 + RS decode + error count + re-encode); the 12 pilot "
+                                                "blocks are skipped (their detection is never used), per-block error counts stay on the "
+                                                "device and are read back once at the end"},
+                "self_supervised_one_trial": {"ms": ms2c1, "blocks_per_s": N / (ms2c1 * 1e-3),
+                                              "what": "harness.eval_by_word alone: one fused step launch + one host sync per block, 200 "
+                                                      "CE+Adam iterations per qualifying block in one launch of online_train_kernel"},
+                "self_supervised_trials": {"trials_per_gpu": R2, "ms": ms2c, "us_per_block_step": ms2c * 1e3 / N,
+                                           "blocks_per_s": world * R2 * N / (ms2c * 1e-3), "symbols_per_s": world * R2 * N * T2 / (ms2c * 1e-3),
+                                           "speedup_vs_one_trial_at_a_time": (R2 * N / ms2c) / (N / ms2c1),
+                                           "mean_ser_by_snr_db": {str(7 + k): float(np.nanmean(rep2[k::6])) for k in range(6)},
+                                           "roofline": training_roofline(st2, R2, 200, 32, False, 1),
+                                           "what": f"{R2} independent trials per GPU (SNR 7..12 dB x seeds, plotter_main.py:117-149) stepping "
+                                                   "together: per block step one byword_step_kernel launch for all trials, one host sync, one "
+                                                   "online_train_kernel launch (gridDim.y = trial) for the trials that train; per trial "
+                                                   "bit-identical to the one-trial run; one all_gather of ser_by_word[300] per trial"},
                 "roofline": None,
-                "note": "one wave of work per launch: bound by launch + host-sync latency, not by a device roofline"})
+                "note": "the joint variants are one wave of work per launch (launch-latency-bound); the self-supervised variant is bound by "
+                        "the training launches, see self_supervised_trials.roofline"})
 
     # ---- configs[4]: Meta-ViterbiNet online retrain + decode, reference defaults (200 / 20 / 10 / 5), replicas
-    def trial_meta(i):
-        m_, r_ = words("time_decay", 7.0 + (i % 6), 200 + i)
-        d_ = make_det()
-        torch.manual_seed(i)
-        return mvn.eval_by_word(d_, m_, r_, 7.0 + (i % 6), GAMMA, nsym, sub, self_supervised=True, online_trainer=mvn.OnlineTrainer(d_, L),
-                                self_supervised_iterations=200, online_meta=True, meta_detector=mvn.META_VNETDetector(16, {"train": T2, "val": T2}),
-                                meta_train_iterations=20, meta_j_num=10, meta_subframes=5, meta_style_online_training=True)
-
-    ms4, rep4 = wall_ms(lambda: mvn.replica_eval(trial_meta, world, rank=rank, world=world, device=dev if backend == "nccl" else "cpu"), dev)
-    ms4 = max_over_ranks(ms4)
+    R4 = int(os.environ.get("MVN_BENCH_TRIALS_META", "56"))
+    kw4 = dict(self_supervised=True, self_supervised_iterations=200, online_meta=True, meta_train_iterations=20, meta_j_num=10,
+               meta_subframes=5, meta_style_online_training=True)
+    ms41, _ = wall_ms(lambda: one_trial("time_decay", 0, 200, **kw4), dev)
+    st4 = {}
+    run4 = trial_batch("time_decay", 200, st4, **kw4)
+    rep4 = mvn.replica_eval(run4, R4 * world, rank=rank, world=world, device=dev if backend == "nccl" else "cpu", batched=True)
+    ms4 = max_over_ranks(st4["ms"])
     out.append({"config": "BASELINE configs[4]: Meta-ViterbiNet online retrain + decode, L=4, pilot-aided, 300 blocks (reference defaults: "
                           "200 full-word iterations per block, every 5 blocks 20 x <=10 MAML steps)",
-                "n_gpus": world, "ms": ms4, "ms_per_block": ms4 / N, "blocks_per_s": world * N / (ms4 * 1e-3),
-                "symbols_per_s": world * N * T2 / (ms4 * 1e-3), "mean_ser_by_trial": [float(v) for v in np.nanmean(rep4, axis=1)],
-                "kernel": "maml_train_groups_kernel + online_train_groups_kernel + " + kfused,
-                "what": f"{world} independent trial(s) (replicas: block k's weights depend on the blocks before it), one all_gather of ser_by_word[300]",
-                "roofline": None, "note": "training passes run one workgroup per 32-sample chunk (5 / 9 CUs per word), gradients exchanged through a workspace with one device-wide barrier per pass: latency-bound, see DESIGN.md 5.6"})
+                "n_gpus": world, "trials_per_gpu": R4, "ms": ms4, "ms_per_block_step": ms4 / N, "blocks_per_s": world * R4 * N / (ms4 * 1e-3),
+                "symbols_per_s": world * R4 * N * T2 / (ms4 * 1e-3),
+                "one_trial": {"ms": ms41, "ms_per_block": ms41 / N, "blocks_per_s": N / (ms41 * 1e-3)},
+                "speedup_vs_one_trial_at_a_time": (R4 * N / ms4) / (N / ms41),
+                "mean_ser_by_snr_db": {str(7 + k): float(np.nanmean(rep4[k::6])) for k in range(6)},
+                "kernel": "maml_train_groups_kernel + online_train_groups_kernel + byword_step_kernel",
+                "what": f"{R4} independent trial(s) per GPU stepping together (replicas: block k's weights depend on the blocks before it); "
+                        "per block step one byword_step_kernel launch, one host sync, and for the trials that train one launch sequence of "
+                        "maml_train_groups_kernel (9 workgroups per trial) and online_train_groups_kernel (5 per trial), never more "
+                        "workgroups per launch than CUs; one all_gather of ser_by_word[300] per trial",
+                "roofline": training_roofline(st4, R4, 200, T2, True, 9),
+                "note": "training passes run one workgroup per 32-sample chunk and trial, gradients exchanged through a per-trial workspace "
+                        "with one device-wide barrier per pass (DESIGN.md 5.6, 5.7)"})
     return out
 
 
@@ -339,6 +403,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--blocks", type=int, default=10000, help="blocks per GPU (BASELINE configs[1]: 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained-rate loop")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0)
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config entries (BASELINE configs[0],[2],[3],[4])")
     ap.add_argument("--skip-fused-count", action="store_true", help="(profiling) keep every fused-kernel dispatch decode-only: no fused-count timing, no FER curve, no by-word configs")
     args = ap.parse_args()
@@ -421,8 +487,38 @@ def main():
         all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
-    total_symbols = float(world) * B * T * args.steps
     ser, fer = mvn.rates_from_counters(counters)
+    # what every rank decoded inside the timed region, gathered so that the line shows N ranks took part (and `value` is
+    # their sum over the max-over-ranks time); the counters' frame count says the same through the all-reduce
+    mine = torch.tensor([B * T * args.steps], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+    per_rank = [mine.clone() for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, mine)
+    symbols_by_rank = [int(t.item()) for t in per_rank]
+    total_symbols = float(sum(symbols_by_rank))
+    collective = {"backend": (dist.get_backend() if world > 1 else None), "world_size": (dist.get_world_size() if world > 1 else 1),
+                  "rccl_version": None, "symbols_by_rank": symbols_by_rank, "frames_all_ranks": int(counters[3].item()),
+                  "frames_expected": world * B * args.steps}
+    try:
+        v = torch.cuda.nccl.version()
+        collective["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception as e:  # noqa: BLE001 (a torch build without the binding: say so instead of failing the bench)
+        collective["rccl_version"] = f"unavailable ({type(e).__name__})"
+
+    # sustained rate: the same step() for >= 2 s (the timed region above is tens of milliseconds), outside `value`
+    sustained = None
+    if rank == 0 and not args.no_sustained:
+        n_sus, t_sus = 0, time.perf_counter()
+        while time.perf_counter() - t_sus < args.sustained_seconds:
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize(dev)
+            n_sus += 20
+        dt_sus = time.perf_counter() - t_sus
+        sustained = {"seconds": dt_sus, "steps": n_sus, "symbols_per_s": n_sus * B * T / dt_sus, "ms_per_step": dt_sus / n_sus * 1e3,
+                     "what": "rank 0's step() back to back for the stated time, one host sync per 20 steps"}
+    if world > 1:
+        dist.barrier()
 
     # FER@SNR / SER@SNR curve (the second half of BASELINE's metric), outside the timed region: fresh words per SNR
     # point on every rank, fused decode+count, one all-reduce of the int64[4] counters per point.
@@ -475,6 +571,8 @@ def main():
                        "blocks_per_gpu": B, "block_length": T, "n_states": S, "snr_db": SNR_DB,
                        "weights": "tests/golden/g7_by_word.npz (trained on the reference)",
                        "parallelism": f"block-sharded x{world}, one all-reduce of int64[4] counters"},
+            "collective": collective,
+            "sustained": sustained,
             "ser_at_snr": ser,
             "fer_at_snr": fer,
             "fer_curve": fer_curve,
@@ -500,7 +598,9 @@ def main():
     configs = [] if args.no_configs else run_configs(dev, rank, world, all_reduce, backend, weights, by_word=not args.skip_fused_count)
     if rank == 0:
         out["configs"] = configs
-        if not args.no_cpu_baseline and world == 1:
+        if sustained is not None:
+            sustained["ratio_to_value"] = sustained["symbols_per_s"] * world / out["value"]  # per-GPU sustained rate x N vs the timed region
+        if not args.no_cpu_baseline:  # rank 0's host cores, at every N (the other ranks wait in the barrier below)
             out["cpu_baseline"] = cpu_baseline([w.cpu().numpy() for w in weights], 3450002)
             out["cpu_baseline_torch_path"] = cpu_baseline_torch_path([w.cpu().numpy() for w in weights], 3450002)
         print(json.dumps(out), flush=True)

@@ -751,6 +751,14 @@ size_t trial_workspace_floats(int S, int groups) {
     return ((maml_groups_workspace_bytes(S, groups) + 255) & ~(size_t)255) / sizeof(float);
 }
 
+// R trials, at most `fit` per launch (workgroups <= CUs): as few launches as possible, of equal size (29 trials with room for
+// 28 run as 15 + 14, not 28 + 1)
+int trials_per_launch(int R, int fit) {
+    fit = std::max(1, fit);
+    const int launches = (R + fit - 1) / fit;
+    return (R + launches - 1) / launches;
+}
+
 // zero the GroupSync at the head of each of `trials` workspace regions
 hipError_t clear_group_syncs(float *workspace, size_t stride_floats, int trials, hipStream_t st) {
     if (trials == 1) return hipMemsetAsync(workspace, 0, sizeof(GroupSync), st);
@@ -791,7 +799,7 @@ int launch_online_train(const mvn_train_trial_t &one, const mvn_train_trial_t *m
         });
     }
     // one workgroup per chunk and trial, never more workgroups in a launch than the device has CUs (all resident at once)
-    const int per_launch = many ? std::max(1, cus / groups) : 1;
+    const int per_launch = many ? trials_per_launch(R, cus / groups) : 1;
     for (int r0 = 0; r0 < R; r0 += per_launch) {
         const int nr = std::min(per_launch, R - r0);
         float *wsr = (float *)workspace + (size_t)r0 * stride;
@@ -843,7 +851,7 @@ int launch_maml_train(const mvn_train_trial_t &one, const mvn_train_trial_t *man
             return (int)hipGetLastError();
         });
     }
-    const int per_launch = many ? std::max(1, cus / groups) : 1;
+    const int per_launch = many ? trials_per_launch(R, cus / groups) : 1;
     for (int r0 = 0; r0 < R; r0 += per_launch) {
         const int nr = std::min(per_launch, R - r0);
         float *wsr = (float *)workspace + (size_t)r0 * stride;

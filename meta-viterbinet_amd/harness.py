@@ -121,21 +121,28 @@ def sharded_eval(detector: Callable, tx: torch.Tensor, rx: torch.Tensor, snr: fl
     return ser, fer, counters
 
 
-def replica_eval(trial: Callable[[int], np.ndarray], n_trials: int, group=None, rank: Optional[int] = None,
-                 world: Optional[int] = None, device=None) -> np.ndarray:
+def replica_eval(trial: Callable, n_trials: int, group=None, rank: Optional[int] = None,
+                 world: Optional[int] = None, device=None, batched: bool = False) -> np.ndarray:
     """Replica mode for the evaluations that do NOT shard within a trial: with online training
     between blocks (eval_by_word with self_supervised / online_meta, trainer.py:292-347) block k's weights depend on the
     blocks before it, so one trial stays on one GPU and the parallel axis is the (SNR x seed x method) grid the reference
     walks serially (plotters/plotter_main.py:117-149).  Rank r runs trials r, r + world, ...; `trial(i)` returns that
     trial's float ser_by_word vector (all trials the same length); ONE all_gather of the float32 vectors (1.2 KB per
     trial) ends the run.  Returns [n_trials, N] (row i = trial i) on every rank.
+    batched=True: `trial` takes the LIST of this rank's trial numbers and returns their vectors as rows [len(list), N] --
+    the rank's trials then advance together on its GPU (trials.eval_by_word_batched) instead of one after the other.
     `device`: where the gathered tensor lives (a CUDA device under backend 'nccl' = RCCL, 'cpu' under gloo)."""
     up = dist.is_available() and dist.is_initialized()
     if rank is None:
         rank = dist.get_rank(group) if up else 0
     if world is None:
         world = dist.get_world_size(group) if up else 1
-    mine = [np.asarray(trial(i), dtype=np.float32).reshape(-1) for i in range(rank, n_trials, world)]
+    ids = list(range(rank, n_trials, world))
+    if batched:
+        rows = np.asarray(trial(ids), dtype=np.float32).reshape(len(ids), -1) if ids else np.zeros((0, 0), np.float32)
+        mine = [rows[k] for k in range(len(ids))]
+    else:
+        mine = [np.asarray(trial(i), dtype=np.float32).reshape(-1) for i in ids]
     per_rank = (n_trials + world - 1) // world
     n = mine[0].shape[0] if mine else 0
     if up and world > 1:  # ranks without a trial still need the vector length for the collective

@@ -191,8 +191,16 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
     if record is not None:
         record.update(nerr=np.zeros((R, N), np.int64), trained=np.zeros((R, N), bool), meta=np.zeros((R, N), bool))
     tables = None
+    timing = None
+    if record is not None and record.get("timing"):
+        import time
+
+        timing = record["timing"] = {"wait": 0.0, "host": 0.0}
+        t_c = time.perf_counter()
     with _lib.on_device(dev):
         for count in range(N):
+            if timing is not None and count:
+                t_c = t_b
             pilot = 1 if count % subframes_in_frame == 0 else 0
             rc = lib.mvn_vnet_byword_step_f32(ctypes.c_void_p(rx.data_ptr() + 4 * count * T), N * T,
                                               ctypes.c_void_p(tx.data_ptr() + 4 * count * K), N * K, *wp, w_stride,
@@ -201,7 +209,13 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
                                               ctypes.c_void_p(sync_dev.data_ptr()), R, T, n_symbols, pilot, S, stream)
             _lib.check(rc, "mvn_vnet_byword_step_f32")
             sync_host.copy_(sync_dev, non_blocking=True)
+            if timing is not None:
+                t_a = time.perf_counter()
             ts.synchronize()  # the one host sync of the step (the reference has one per trial and block, trainer.py:305)
+            if timing is not None:
+                t_b = time.perf_counter()
+                timing["wait"] += t_b - t_a
+                timing["host"] += t_a - t_c
             if status_np.any():
                 raise _lib.MvnError(f"trials {np.flatnonzero(status_np).tolist()}: {lib.mvn_strerror(-7).decode()}")
             ser = ser_from_errors(nerr_np, K)  # the reference's value bit for bit (metrics.py:13-16)

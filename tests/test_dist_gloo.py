@@ -88,6 +88,9 @@ def _worker(rank, world, port, q):
                                     rs_decoder=_oracle_rs)
         # replica mode (configs that do not shard within a trial): 5 trials over 2 ranks, one all_gather
         rep = mvn.replica_eval(_replica_trial, 5)
+        # ... and with each rank's trials run as one batch (trials.eval_by_word_batched's calling convention)
+        repb = mvn.replica_eval(lambda ids: np.stack([_replica_trial(i) for i in ids]), 5, batched=True)
+        assert np.array_equal(rep, repb)
         q.put((rank, counters.tolist(), c2.tolist(), ser, fer, c3.tolist(), rep.tolist()))
     finally:
         dist.destroy_process_group()
@@ -116,6 +119,7 @@ def test_world2_counters_equal_single_process():
     assert coded1[1] == 21 * 24
     rep1 = mvn.replica_eval(_replica_trial, 5)  # no process group: every trial on this process
     assert rep1.shape == (5, 300) and np.array_equal(rep1[3], _replica_trial(3))
+    assert np.array_equal(rep1, mvn.replica_eval(lambda ids: np.stack([_replica_trial(i) for i in ids]), 5, batched=True))
     for rank, counters, c2, ser, fer, c3, rep in res:
         assert np.array_equal(np.asarray(rep, np.float32), rep1)  # same [trial, block] table on every rank
         assert counters == c1.tolist()  # identical integers on every rank

@@ -83,3 +83,36 @@ def test_bench_self_launch_two_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
     assert out["value"] > 0 and np.isfinite(out["value"])
+    _check_collective_fields(out, 2, 512, 2)
+
+
+def _check_collective_fields(out, world, blocks, steps):
+    """The fields that let a reader of the JSON line confirm that N ranks took part in the collective."""
+    c = out["collective"]
+    assert c["world_size"] == world and c["backend"] == "gloo"
+    assert c["symbols_by_rank"] == [blocks * 1000 * steps] * world
+    assert c["frames_all_ranks"] == c["frames_expected"] == world * blocks * steps  # the all-reduced counters saw every rank
+    assert out["value"] == pytest.approx(sum(c["symbols_by_rank"]) / (out["ms_per_step"] * 1e-3 * steps), rel=1e-6)
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_launch_four_ranks_with_configs():
+    """The multi-rank control flow of the whole bench line (headline + every per-config entry: block-sharded configs,
+    replica configs with R trials per rank, the cpu baseline on rank 0) with four gloo ranks sharing this box's GPU -- the
+    rehearsal of the 8-GPU run the driver launches (the GPU box admits at most 6 processes on the card at once, so 8 ranks
+    cannot be rehearsed here)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(MVN_BENCH_BACKEND="gloo", MVN_BENCH_TRIALS_SELFSUP="6", MVN_BENCH_TRIALS_META="3")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+                        "--blocks", "512", "--sustained-seconds", "0.2"], env=env, capture_output=True, text=True, timeout=860)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4
+    _check_collective_fields(out, 4, 512, 2)
+    assert out["cpu_baseline"]["value"] > 0 and out["sustained"]["symbols_per_s"] > 0
+    cfg = {c["config"].split(":")[0]: c for c in out["configs"]}
+    assert cfg["BASELINE configs[3]"]["frames"] == 4 * 125000  # all ranks' blocks in the all-reduced counters
+    assert cfg["BASELINE configs[2]"]["self_supervised_trials"]["trials_per_gpu"] == 6
+    assert cfg["BASELINE configs[4]"]["trials_per_gpu"] == 3 and cfg["BASELINE configs[4]"]["blocks_per_s"] > 0

@@ -1,0 +1,13 @@
+import os, sys, time
+R = int(sys.argv[1]); flow = sys.argv[2]
+sys.argv=[sys.argv[0]]
+exec(open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), 'tools/time_trials.py')).read().split("Rs = [int(a)")[0])
+name = [k for k in FLOWS if flow in k][0]
+coef, kw = FLOWS[name]
+ws = [words(coef, 7.0 + (i % 6), 100 + i) for i in range(R)]
+msg, rx = torch.stack([a for a, _ in ws]), torch.stack([b for _, b in ws])
+bank = TrialBank([w] * R, 16, L, dev)
+draws = [TrialDraws(100 + i, dev) for i in range(R)]
+ser = eval_by_word_batched(bank, msg, rx, nsym, sub, draws, **kw)
+torch.cuda.synchronize()
+print(R, name, ser.mean())

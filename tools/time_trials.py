@@ -1,0 +1,69 @@
+"""Blocks/s of R by-word evaluations stepping together on one GPU (trials.eval_by_word_batched) against one trial alone
+(harness.eval_by_word), for the two BASELINE flows with online training: configs[2] with self-supervised minibatch
+iterations and configs[4] (Meta-ViterbiNet).  usage: time_trials.py [R ...]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, ROOT)
+import meta_viterbinet_amd as mvn  # noqa: E402
+from meta_viterbinet_amd.trials import TrialBank, TrialDraws, eval_by_word_batched  # noqa: E402
+
+dev = torch.device("cuda:0")
+N, K, nsym, L, sub, T = 300, 120, 2, 4, 25, 136
+g7 = np.load(os.path.join(ROOT, "tests", "golden", "g7_by_word.npz"))
+w = [g7[f"w{i}"] for i in range(6)]
+
+
+def words(coef, snr, seed):
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    msg = torch.randint(0, 2, (N, K), generator=gen, device=dev).float()
+    cw = mvn.rs_encode(msg, nsym)
+    if coef == "cost2100":
+        h = np.concatenate([mvn.estimate_channel(L, 0.2, "cost2100", index=i) for i in range(N)])
+    else:
+        h = np.concatenate([mvn.estimate_channel(L, 0.2, "time_decay", fading=True, index=i, fading_taps_type=2) for i in range(N)])
+    return msg, mvn.transmit(cw, h, snr, L, torch.randn(N, T, generator=gen, device=dev))
+
+
+FLOWS = {"configs[2] self-supervised (200 minibatch iterations / block)": ("cost2100", dict(self_supervised=True, self_supervised_iterations=200)),
+         "configs[4] Meta-ViterbiNet (200 / 20 / 10 / 5)": ("time_decay", dict(self_supervised=True, self_supervised_iterations=200, online_meta=True,
+                                                                meta_train_iterations=20, meta_j_num=10, meta_subframes=5,
+                                                                meta_style_online_training=True))}
+Rs = [int(a) for a in sys.argv[1:]] or [1, 8, 16, 28, 32, 64]
+for name, (coef, kw) in FLOWS.items():
+    print(name)
+    det = mvn.VNETDetector(16, {"train": T, "val": T}).to(dev)
+    with torch.no_grad():
+        for p, a in zip(det.parameters(), w):
+            p.copy_(torch.tensor(a))
+    m, r = words(coef, 10.0, 1)
+    for rep in range(2):
+        det_ = mvn.VNETDetector(16, {"train": T, "val": T}).to(dev)
+        det_.load_state_dict(det.state_dict())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ser = mvn.eval_by_word(det_, m, r, 10.0, 0.2, nsym, sub, online_trainer=mvn.OnlineTrainer(det_, L),
+                               meta_detector=mvn.META_VNETDetector(16, {"train": T, "val": T}), draws=TrialDraws(1, dev), **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print(f"  sequential, 1 trial : {dt * 1e3:8.1f} ms  {N / dt:9.0f} blocks/s  mean ser {ser.mean():.5f}")
+    for R in Rs:
+        ws = [words(coef, 7.0 + (i % 6), 100 + i) for i in range(R)]
+        msg, rx = torch.stack([a for a, _ in ws]), torch.stack([b for _, b in ws])
+        for rep in range(2):
+            bank = TrialBank([w] * R, 16, L, dev)
+            draws = [TrialDraws(100 + i, dev) for i in range(R)]
+            if "meta" not in name:
+                for d in draws:
+                    d.batches(0, N, T, 200, 32)  # the draw tables are inputs, like the words
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ser = eval_by_word_batched(bank, msg, rx, nsym, sub, draws, **kw)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        print(f"  batched, R = {R:3d}     : {dt * 1e3:8.1f} ms  {R * N / dt:9.0f} blocks/s  mean ser {ser.mean():.5f}  steps {int(bank.step.sum())}")
