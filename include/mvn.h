@@ -18,13 +18,19 @@
  *   - decisions are written as fp32 {0.,1.} like the reference's decoded_word
  *     (va_detector.py:90-93); columns >= T of `dec` are not touched (caller zero-fills).
  *   - arithmetic is IEEE fp32 with one rounding per reference operation; results are
- *     bit-identical to oracle/mvn_oracle.c for finite inputs, for +-inf, and for NaN samples in y
- *     (all branch costs of that symbol become NaN, as in the reference).  mvn_acs_block_f32 propagates NaN like
- *     torch.min.  DEVIATION, pinned by tests/test_gpu_parity.py::test_partial_nan_costs_are_dropped_by_the_sweeps: inside
- *     the sweeps a NaN in only ONE of a state's two candidates (possible through NaN in some of a symbol's branch
- *     costs, priors or last-layer weights only) is dropped -- the stage is v_min_f32 = fminf -- where torch.min would
- *     return NaN; a state both of whose candidates are NaN becomes NaN, and the decision rule (first NaN, else first
- *     minimum) is torch.argmin's.
+ *     bit-identical to oracle/mvn_oracle.c for finite inputs, for +-inf, and for NaN -- in the samples y, in the weights
+ *     and in the state priors: mvn_acs_block_f32, mvn_va_decode_f32, mvn_vnet_decode_f32 (every route, every S),
+ *     mvn_vnet_decode_count_f32 and mvn_vnet_byword_step_f32 follow torch.min / torch.argmin (NaN when either candidate is
+ *     NaN; the first NaN, else the first minimum).  The fast kernels' ACS stage is v_min_f32 (minNum), which agrees with
+ *     torch.min unless SOME BUT NOT ALL of a symbol's branch costs are NaN; from y, weights and priors that takes a
+ *     non-finite (or > 1e14 in magnitude) weight or prior, which the kernels look for once per launch and then run their
+ *     NaN-propagating form (16-state kernels) or are followed by a guard launch of the generic kernel that re-decodes the
+ *     affected blocks (sweep_kernel<S, MODE, true>: an early-exit no-op otherwise).
+ *     REMAINING DEVIATION, pinned by tests/test_gpu_parity.py::test_partial_nan_costs_are_dropped_by_the_sweeps:
+ *     mvn_acs_sweep_f32 takes MATERIALISED costs, which nothing vouches for: its specialised kernels drop a NaN that sits
+ *     in only one of a state's two candidates (a state both of whose candidates are NaN becomes NaN, and the decision rule
+ *     is torch.argmin's); S = 2, buffers that are not 16-byte aligned and MVN_GENERIC_SWEEP=1 take the generic kernel,
+ *     which follows torch.min there too.
  */
 #ifndef MVN_H_
 #define MVN_H_

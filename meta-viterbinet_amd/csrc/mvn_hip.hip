@@ -81,8 +81,22 @@ __device__ __forceinline__ float va_cost(float y, float prior) {
 // lane, one block per wave).  Path metrics live in VGPRs; the predecessor shuffle
 // out[s] = min(a[2s%S], a[(2s+1)%S]) goes through a per-wave LDS row (ds_write_b32 +
 // ds_read_b64); the running argmin is a lexicographic (value,index) xor-butterfly.
+// The ACS minimum here is torch.min's (NaN if either candidate is NaN, trellis_utils.py:30), not minNum: this kernel is
+// also the GUARD of the specialised VA / two-kernel ViterbiNet routes, whose v_min_f32 stages drop a NaN that sits in one
+// candidate only.  That can only matter when a state prior / a weight is non-finite or absurdly large, so the guard launch
+// (GUARD = true, right after the fast kernel on the same stream) scans exactly those -- the priors of its own blocks, or
+// the six weight arrays -- and returns at once unless it finds one, in which case it decodes its blocks again and
+// overwrites the fast kernel's decisions and final metrics.
 // -------------------------------------------------------------------------------------------
 enum { MODE_COST = 0, MODE_NEGLOGIT = 1, MODE_VA = 2 };
+
+constexpr float kStrictMinBoundG = 1e14f;  // = kStrictMinBound (vnet16_fused.inc, included below)
+struct GuardWeights {  // the ViterbiNet weights a MODE_NEGLOGIT guard scans (lengths in floats); unused otherwise
+    const float *w[6];
+    int n[6];
+};
+// torch.min(dim) over (a, b) in index order: the first NaN wins, else the smaller, ties to a (oracle: min2_torch)
+__device__ __forceinline__ float min2_torch_dev(float a, float b) { return a != a ? a : (!(b >= a) ? b : a); }
 
 template <int S>
 struct SweepCfg {
@@ -94,10 +108,10 @@ struct SweepCfg {
 
 constexpr int kSweepWaves = 4;
 
-template <int S, int MODE>
+template <int S, int MODE, bool GUARD = false>
 __global__ __launch_bounds__(64 * kSweepWaves) void sweep_kernel(
     const float *__restrict__ src, int64_t src_ld, const float *__restrict__ priors, int64_t Bp,
-    float *__restrict__ dec, int64_t dec_ld, float *__restrict__ final_metric, int64_t B, int T) {
+    float *__restrict__ dec, int64_t dec_ld, float *__restrict__ final_metric, int64_t B, int T, const GuardWeights gw) {
     using C = SweepCfg<S>;
     constexpr int LPB = C::LPB, R = C::R, G = C::G, TC = C::TC;
     __shared__ float lds[kSweepWaves][64 * R];
@@ -117,6 +131,18 @@ __global__ __launch_bounds__(64 * kSweepWaves) void sweep_kernel(
         m[r] = 0.0f;  // va_detector.py:84
         pr[r] = 0.0f;
         if (MODE == MODE_VA) pr[r] = priors[(bc % Bp) * S + sl + LPB * r];
+    }
+    if (GUARD) {  // wave-uniform: nothing to repair unless a prior / weight can produce partially-NaN branch costs
+        bool odd = false;
+        if (MODE == MODE_VA) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) odd |= !(fabsf(pr[r]) < kStrictMinBoundG);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+                for (int e = lane; e < gw.n[a]; e += 64) odd |= !(fabsf(gw.w[a][e]) < kStrictMinBoundG);
+        }
+        if (!__any(odd)) return;
     }
 
     const float *base = (MODE == MODE_VA) ? src + bc * src_ld : src + bc * (int64_t)T * S;
@@ -182,7 +208,7 @@ __global__ __launch_bounds__(64 * kSweepWaves) void sweep_kernel(
                 for (int r = 0; r < R; ++r) {
                     int p0 = (2 * (sl + LPB * r)) % S;
                     float2 v = *reinterpret_cast<const float2 *>(&row[p0]);
-                    m[r] = fminf(v.x, v.y);
+                    m[r] = min2_torch_dev(v.x, v.y);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -197,16 +223,17 @@ __global__ __launch_bounds__(64 * kSweepWaves) void sweep_kernel(
     }
 }
 
-template <int MODE>
+template <int MODE, bool GUARD = false>
 int launch_sweep(const float *src, int64_t src_ld, const float *priors, int64_t Bp, float *dec,
-                 int64_t dec_ld, float *final_metric, int64_t B, int T, int S, hipStream_t st) {
+                 int64_t dec_ld, float *final_metric, int64_t B, int T, int S, hipStream_t st,
+                 const GuardWeights gw = GuardWeights{}) {
     if (B == 0 || T == 0) return MVN_OK;
 #define MVN_SWEEP_CASE(SS)                                                                       \
     case SS: {                                                                                   \
         constexpr int per_wg = kSweepWaves * SweepCfg<SS>::G;                                    \
         int64_t grid = (B + per_wg - 1) / per_wg;                                                \
-        hipLaunchKernelGGL((sweep_kernel<SS, MODE>), dim3((unsigned)grid), dim3(64 * kSweepWaves), \
-                           0, st, src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T);     \
+        hipLaunchKernelGGL((sweep_kernel<SS, MODE, GUARD>), dim3((unsigned)grid), dim3(64 * kSweepWaves), \
+                           0, st, src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, gw);  \
         break;                                                                                   \
     }
     switch (S) {
@@ -686,35 +713,46 @@ void sweep_kernel_name(SweepKind k, int S, const void *dec, int64_t dec_ld, char
     }
 }
 
+// gw: the ViterbiNet weights when the costs are the logits of the two-kernel route (MODE_NEGLOGIT), else NULL
 template <int MODE>
 int dispatch_sweep(const float *src, int64_t src_ld, const float *priors, int64_t Bp, float *dec, int64_t dec_ld,
-                   float *final_metric, int64_t B, int T, int S, hipStream_t st) {
-    switch (plan_sweep<MODE>(src, dec, dec_ld, B, S)) {
+                   float *final_metric, int64_t B, int T, int S, hipStream_t st, const GuardWeights *gw = nullptr) {
+    int rc = -1;
+    const SweepKind kind = plan_sweep<MODE>(src, dec, dec_ld, B, S);
+    switch (kind) {
         case SK_VA256_WAVE:
-            if constexpr (MODE == MODE_VA) return launch_va256_wave(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
+            if constexpr (MODE == MODE_VA) rc = launch_va256_wave(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
             break;
         case SK_VA_INPLACE:
-            if constexpr (MODE == MODE_VA) return launch_va_inplace(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, S, st);
+            if constexpr (MODE == MODE_VA) rc = launch_va_inplace(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, S, st);
             break;
         case SK_VA16_QUAD:
-            if constexpr (MODE == MODE_VA) return launch_va16_quad(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
+            if constexpr (MODE == MODE_VA) rc = launch_va16_quad(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
             break;
-        case SK_VA16_TILE:
+        case SK_VA16_TILE:  // (strict by itself: va16_tile.inc)
             if constexpr (MODE == MODE_VA) return launch_va16_tile(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
             break;
         case SK_SWEEP_INPLACE:
-            if constexpr (MODE != MODE_VA) return launch_sweep_inplace<MODE>(src, dec, dec_ld, final_metric, B, T, S, st);
+            if constexpr (MODE != MODE_VA) rc = launch_sweep_inplace<MODE>(src, dec, dec_ld, final_metric, B, T, S, st);
             break;
         case SK_S16_QUAD:
-            if constexpr (MODE != MODE_VA) return launch_sweep16_quad<MODE>(src, dec, dec_ld, final_metric, B, T, st);
+            if constexpr (MODE != MODE_VA) rc = launch_sweep16_quad<MODE>(src, dec, dec_ld, final_metric, B, T, st);
             break;
         case SK_S16_LDS:
-            if constexpr (MODE != MODE_VA) return launch_sweep16_lds<MODE>(src, dec, dec_ld, final_metric, B, T, st);
+            if constexpr (MODE != MODE_VA) rc = launch_sweep16_lds<MODE>(src, dec, dec_ld, final_metric, B, T, st);
             break;
-        case SK_S16_ROWS: return launch_sweep16_rows<MODE>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
+        case SK_S16_ROWS: rc = launch_sweep16_rows<MODE>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st); break;
         default: break;
     }
-    return launch_sweep<MODE>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, S, st);
+    if (rc < 0)  // the generic kernel (its ACS minimum is torch.min's: no guard needed)
+        return launch_sweep<MODE>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, S, st);
+    if (rc) return rc;
+    // the specialised kernels' v_min_f32 stages drop a NaN that sits in one candidate only: the guard launch repairs the
+    // blocks whose state priors (VA) / whose weights (ViterbiNet logits) can produce such costs, and is a no-op otherwise
+    if constexpr (MODE == MODE_VA) return launch_sweep<MODE_VA, true>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, S, st);
+    if constexpr (MODE == MODE_NEGLOGIT)
+        if (gw) return launch_sweep<MODE_NEGLOGIT, true>(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, S, st, *gw);
+    return MVN_OK;
 }
 
 bool valid_states(int S) { return S >= 2 && S <= 256 && (S & (S - 1)) == 0; }
@@ -1032,8 +1070,9 @@ int mvn_vnet_decode_f32(const float *y, int64_t y_ld, const float *W1, const flo
         float *lg = logits_out ? logits_out + (size_t)b0 * T * S : buf;
         int rc = launch_mlp(y + b0 * y_ld, y_ld, T, nb * T, W1, b1, W2, b2, W3, b3, lg, S, st);
         if (rc) return rc;
+        const GuardWeights gw = {{W1, b1, W2, b2, W3, b3}, {kH1, kH1, kH2 * kH1, kH2, S * kH2, S}};
         rc = dispatch_sweep<MODE_NEGLOGIT>(lg, 0, nullptr, 1, dec + b0 * dec_ld, dec_ld,
-                                         final_metric ? final_metric + b0 * S : nullptr, nb, T, S, st);
+                                         final_metric ? final_metric + b0 * S : nullptr, nb, T, S, st, &gw);
         if (rc) return rc;
     }
     return MVN_OK;

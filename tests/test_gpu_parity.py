@@ -1175,10 +1175,12 @@ def test_acs_block_propagates_nan_like_torch_min(oracle, dev):
 
 @pytest.mark.parametrize("S,variant", [(4, ""), (16, "rows"), (16, "lds"), (16, "quad"), (16, "inplace"), (16, "generic"),
                                        (64, ""), (64, "generic"), (256, "")])
-def test_partial_nan_costs_are_dropped_by_the_sweeps(dev, monkeypatch, S, variant):
-    """The documented deviation of include/mvn.h: inside a sweep the ACS minimum is v_min_f32 (= fminf), which drops a
-    NaN that sits in only ONE of a state's two candidates, where torch.min would return NaN.  Pinned against a NumPy
-    model with np.fmin; the decision rule (first NaN, else first minimum) is np.argmin's = torch.argmin's."""
+def test_partial_nan_costs_are_dropped_by_the_sweeps(oracle, dev, monkeypatch, S, variant):
+    """The documented deviation of include/mvn.h, now confined to mvn_acs_sweep_f32 over MATERIALISED costs: its specialised
+    kernels' ACS minimum is v_min_f32 (= fminf), which drops a NaN that sits in only ONE of a state's two candidates, where
+    torch.min would return NaN.  Pinned against a NumPy model with np.fmin; the decision rule (first NaN, else first
+    minimum) is np.argmin's = torch.argmin's.  The generic kernel (S = 2, unaligned buffers, MVN_GENERIC_SWEEP=1) takes
+    torch.min's rule and is compared with the oracle."""
     rng = np.random.RandomState(S)
     B, T = 6, 40
     cost = rng.normal(0, 2, (B, T, S)).astype(np.float32)
@@ -1192,18 +1194,97 @@ def test_partial_nan_costs_are_dropped_by_the_sweeps(dev, monkeypatch, S, varian
         monkeypatch.setenv("MVN_SWEEP_INPLACE", "1")
     elif variant == "generic":
         monkeypatch.setenv("MVN_GENERIC_SWEEP", "1")
-    want_dec = np.zeros((B, T), np.float32)
-    m = np.zeros((B, S), np.float32)
-    idx = np.arange(S)
-    with np.errstate(invalid="ignore"):
-        for t in range(T):
-            want_dec[:, t] = np.argmin(m, axis=1) % 2
-            a = m + cost[:, t]
-            m = np.fmin(a[:, (2 * idx) % S], a[:, (2 * idx + 1) % S])
+    if variant == "generic":
+        want_dec, m = oracle.acs_sweep(cost)
+    else:
+        want_dec = np.zeros((B, T), np.float32)
+        m = np.zeros((B, S), np.float32)
+        idx = np.arange(S)
+        with np.errstate(invalid="ignore"):
+            for t in range(T):
+                want_dec[:, t] = np.argmin(m, axis=1) % 2
+                a = m + cost[:, t]
+                m = np.fmin(a[:, (2 * idx) % S], a[:, (2 * idx + 1) % S])
     dec, fm = mvn.acs_sweep(torch.tensor(cost, device=dev), return_final=True)
     assert np.array_equal(_np(fm), m, equal_nan=True)
     assert np.array_equal(_np(dec), want_dec)
-    assert np.isnan(m[2]).all() and not np.isnan(m[0]).all()
+    assert np.isnan(m[2]).all() and (variant == "generic" or not np.isnan(m[0]).all())
+
+
+VNET_NAN_ROUTES = [(16, {"MVN_COOP": "1"}), (16, {"MVN_COOP": "0"}), (16, {"MVN_COOP": "0", "MVN_FUSEDN": "4"}),
+                   (16, {"MVN_UNFUSED": "1", "MVN_SWEEP16": "rows"}), (16, {"MVN_UNFUSED": "1", "MVN_SWEEP16": "lds"}),
+                   (16, {"MVN_UNFUSED": "1", "MVN_SWEEP16": "quad"}), (16, {"MVN_UNFUSED": "1", "MVN_SWEEP_INPLACE": "1"}),
+                   (4, {}), (8, {}), (64, {}), (64, {"MVN_GENERIC_SWEEP": "1"}), (256, {}), (2, {})]
+
+
+@pytest.mark.parametrize("S,env", VNET_NAN_ROUTES, ids=[f"S{s}-" + "-".join(f"{k[4:]}{v}" for k, v in e.items()) for s, e in VNET_NAN_ROUTES])
+@pytest.mark.parametrize("what", ["nan_w3", "inf_b3", "nan_b3_two_states", "huge_w3"])
+def test_vnet_partial_nan_follows_torch_min(oracle, dev, monkeypatch, S, env, what):
+    """torch.min (trellis_utils.py:30) returns NaN when EITHER candidate of a state is NaN.  One non-finite entry in the
+    last layer makes the branch cost of one state NaN at every symbol and the others finite: every route of
+    mvn_vnet_decode_f32 (fused one-wave-per-block and workgroup-per-block kernels, the two-kernel routes, every S) must give
+    the ORACLE's decisions and final metrics (oracle/mvn_oracle.c: min2_torch), not minNum's."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.RandomState(S + len(what))
+    B, T = 9, 75
+    w = _rand_weights(S, rng)
+    if what == "nan_w3":
+        w[4][rng.randint(S), rng.randint(50)] = np.nan
+    elif what == "inf_b3":
+        w[5][S - 1] = np.inf  # logit +inf, cost -inf for one state: -inf metrics, no NaN, same minima either way
+    elif what == "nan_b3_two_states":
+        w[5][0] = np.nan
+        w[5][S // 2] = np.nan
+    else:
+        w[4][0, 3] = 3e30     # finite but absurd: the strict path is taken and must still be the exact minimum
+    y = rng.normal(0, 1.5, (B, T)).astype(np.float32)
+    det = _vnet_with(w, S, T, dev)
+    lib, st = mvn._lib.load(), mvn._lib.current_stream(dev)
+    yt = torch.tensor(y, device=dev)
+    dec, fm = torch.full((B, T), 7.0, device=dev), torch.empty(B, S, device=dev)
+    ws = torch.empty(B * T * S * 4, dtype=torch.uint8, device=dev)
+    rc = lib.mvn_vnet_decode_f32(mvn._lib.ptr(yt), T, *[mvn._lib.ptr(p) for p in det.parameters()], mvn._lib.ptr(dec), T, None,
+                                 mvn._lib.ptr(fm), mvn._lib.ptr(ws), ws.numel(), B, T, S, st)
+    assert rc == 0
+    with np.errstate(all="ignore"):
+        rdec, rfm = oracle.vnet_decode(y, w, want_final=True)
+    assert np.array_equal(_np(dec), rdec)
+    assert np.array_equal(_np(fm), rfm, equal_nan=True)
+    if what in ("nan_w3", "nan_b3_two_states"):
+        assert np.isnan(rfm).all()  # the NaN state reaches every state within L steps under torch.min
+
+
+VA_NAN_ROUTES = [(16, {"MVN_VA16": "tile"}), (16, {"MVN_VA16": "rows"}), (16, {"MVN_VA16": "quad"}), (16, {"MVN_VA_INPLACE": "1"}),
+                 (16, {"MVN_GENERIC_SWEEP": "1"}), (2, {}), (4, {}), (8, {}), (32, {}), (64, {}), (128, {}), (256, {}),
+                 (256, {"MVN_VA256": "inplace"})]
+
+
+@pytest.mark.parametrize("S,env", VA_NAN_ROUTES, ids=[f"S{s}-" + "-".join(f"{k[4:]}{v}" for k, v in e.items()) for s, e in VA_NAN_ROUTES])
+def test_va_partial_nan_prior_follows_torch_min(oracle, dev, monkeypatch, S, env):
+    """One NaN state prior (and, in another block, an infinite one) with per-block prior rows: the branch cost of that state
+    is NaN at every symbol of that block only.  Every route of mvn_va_decode_f32 gives the oracle's (torch.min's) decisions
+    and final metrics for the affected blocks and leaves the others alone."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.RandomState(S)
+    B, T = 70, 61
+    pri = rng.normal(0, 1, (B, S)).astype(np.float32)
+    pri[3, rng.randint(S)] = np.nan
+    pri[40, S - 1] = np.nan
+    pri[41, 0] = np.inf
+    pri[69, 1 % S] = -np.inf
+    y = rng.normal(0, 1.5, (B, T)).astype(np.float32)
+    y[41, 20] = np.inf  # inf - inf = NaN for one state of one symbol
+    lib, st = mvn._lib.load(), mvn._lib.current_stream(dev)
+    yt, pt = torch.tensor(y, device=dev), torch.tensor(pri, device=dev)
+    dec, fm = torch.full((B, T), 7.0, device=dev), torch.empty(B, S, device=dev)
+    assert lib.mvn_va_decode_f32(mvn._lib.ptr(yt), T, mvn._lib.ptr(pt), B, mvn._lib.ptr(dec), T, mvn._lib.ptr(fm), B, T, S, st) == 0
+    with np.errstate(all="ignore"):
+        rdec, rfm = oracle.va_decode(y, pri)
+    assert np.array_equal(_np(dec), rdec)
+    assert np.array_equal(_np(fm), rfm, equal_nan=True)
+    assert np.isnan(rfm[3]).all() and np.isnan(rfm[40]).all() and np.isfinite(rfm[5]).all()
 
 
 # ---------------------------------------------------------------- BASELINE configs at their full sizes
