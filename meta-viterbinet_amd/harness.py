@@ -186,7 +186,7 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
                  MAML: bool = True, window_size: int = 1, meta_train_iterations: int = 20, meta_j_num: int = 10,
                  meta_subframes: int = 5, meta_style_online_training: bool = False,
                  graphed_meta: bool = True, hip_meta: bool = True, initial_buffer=None, weights_init: str = "last_frame",
-                 meta_training_weights=None, draws=None, fused_step: bool = True) -> np.ndarray:
+                 meta_training_weights=None, draws=None, fused_step: bool = True, observer=None) -> np.ndarray:
     """Sequential per-block online evaluation: counterpart of Trainer.eval_by_word (trainer.py:267-354).  Everything but the
     control flow stays on the GPU:
         for every block k:  detect (B=1)  ->  data block: RS decode, ser, RS re-encode | pilot: encode the known word
@@ -208,7 +208,10 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
     draws: a trials.TrialDraws -- the minibatches and j_hat values come from this trial's own streams instead of the global
     generators (the reference's are unseeded), which is what makes a run replayable inside trials.eval_by_word_batched.
     fused_step: a 16-state ViterbiNet detector with nsym <= 8 takes ONE launch per block (mvn_vnet_byword_step_f32:
-    detect, RS decode, error count, re-encode); False keeps the four separate launches (the cross-check in the tests)."""
+    detect, RS decode, error count, re-encode); False keeps the four separate launches (the cross-check in the tests).
+    observer: called at the end of every block of the update branches with a dict {count, ser, pushed, buffer_rx, buffer_tx,
+    meta: (support_idx [n, W], query_idx [n]) or None, trained, batch_idx, detector, saved_detector}: what a test needs to
+    replay the block's updates on another implementation (tests/test_gpu_replay.py)."""
     import copy
 
     from .meta import GraphedMetaStep, copy_model, meta_train_loop
@@ -274,6 +277,7 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
     for count in range(N):
         transmitted_word, received_word = tx[count].reshape(1, -1), rx[count].reshape(1, -1)
         pilot = count % subframes_in_frame == 0
+        seen = {"count": count, "meta": None, "trained": False, "batch_idx": None} if observer is not None else None
         if fused:  # ONE launch: detect, RS decode, error count, re-encode (pilot: encode the known word)
             detected_word, encoded_word = _byword_step(detector, received_word, transmitted_word, n_symbols, pilot, nerr1)
             ser = 0.0 if pilot else float(_metrics.ser_from_errors(int(nerr1.item()), K))  # calculate_error_rates (:301)
@@ -317,6 +321,8 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
                     sup.append(j_hat_values.reshape(-1, 1) + support_idx.reshape(1, -1) + 1)
                     qry.append(j_hat_values + query_idx + 1)
                 online_trainer.maml_training(buffer_rx, buffer_tx, torch.cat(sup), torch.cat(qry), meta_lr, MAML)
+                if seen is not None:
+                    seen["meta"] = (torch.cat(sup), torch.cat(qry))
             else:
                 if graphed_meta and meta_step is None:  # captured once: one hipGraph replay per MAML step from here on
                     meta_step = GraphedMetaStep(detector, meta_detector, online_trainer, window_size, rx.shape[1], meta_lr,
@@ -336,9 +342,17 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
             batch_idx = None
             if draws is not None and not meta_style_online_training:
                 batch_idx = draws.batches(count, N, rx.shape[1], self_supervised_iterations, online_trainer.train_minibatch_size)
+            if seen is not None and batch_idx is None and not meta_style_online_training:
+                batch_idx = online_trainer.select_batches(rx.shape[1], self_supervised_iterations)  # drawn here to be shown
             online_trainer.online_training(buffer_tx[-1].reshape(1, -1), buffer_rx[-1].reshape(1, -1),
                                            iterations=self_supervised_iterations, batch_idx=batch_idx,
                                            full_word=meta_style_online_training)
+            if seen is not None:
+                seen.update(trained=True, batch_idx=batch_idx)
+        if seen is not None:
+            seen.update(ser=ser, pushed=ser <= ser_thresh, buffer_rx=buffer_rx, buffer_tx=buffer_tx, detector=detector,
+                        saved_detector=saved_detector)
+            observer(seen)
     if online_trainer is not None:
         online_trainer.check_status()
     return ser_by_word
