@@ -209,9 +209,10 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
     generators (the reference's are unseeded), which is what makes a run replayable inside trials.eval_by_word_batched.
     fused_step: a 16-state ViterbiNet detector with nsym <= 8 takes ONE launch per block (mvn_vnet_byword_step_f32:
     detect, RS decode, error count, re-encode); False keeps the four separate launches (the cross-check in the tests).
-    observer: called at the end of every block of the update branches with a dict {count, ser, pushed, buffer_rx, buffer_tx,
-    meta: (support_idx [n, W], query_idx [n]) or None, trained, batch_idx, detector, saved_detector}: what a test needs to
-    replay the block's updates on another implementation (tests/test_gpu_replay.py)."""
+    observer: called at the end of every block of the update branches with a dict {stage: 'end', count, ser, pushed,
+    buffer_rx, buffer_tx, meta: (support_idx [n, W], query_idx [n]) or None, trained, batch_idx, detector, saved_detector},
+    and with stage 'meta' right after a meta-learning update launched by the HIP kernel: what a test needs to replay the
+    block's updates on another implementation (tests/test_gpu_replay.py)."""
     import copy
 
     from .meta import GraphedMetaStep, copy_model, meta_train_loop
@@ -336,6 +337,9 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
                             meta_train_loop(detector, meta_detector, online_trainer, buffer_rx, buffer_tx,
                                             j_hat + support_idx + 1, j_hat + query_idx + 1, meta_lr, MAML)
             copy_model(source_model=detector, dest_model=saved_detector)
+            if seen is not None and seen["meta"] is not None:
+                observer(dict(seen, stage="meta", detector=detector, saved_detector=saved_detector, buffer_rx=buffer_rx,
+                              buffer_tx=buffer_tx))
         if self_supervised and ser <= ser_thresh:  # :345-347
             if meta_style_online_training:
                 copy_model(source_model=saved_detector, dest_model=detector)  # metavnet_trainer.py:59
@@ -350,7 +354,7 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
             if seen is not None:
                 seen.update(trained=True, batch_idx=batch_idx)
         if seen is not None:
-            seen.update(ser=ser, pushed=ser <= ser_thresh, buffer_rx=buffer_rx, buffer_tx=buffer_tx, detector=detector,
+            seen.update(stage="end", ser=ser, pushed=ser <= ser_thresh, buffer_rx=buffer_rx, buffer_tx=buffer_tx, detector=detector,
                         saved_detector=saved_detector)
             observer(seen)
     if online_trainer is not None:
