@@ -88,10 +88,11 @@ def _replay(dev, w0, msg, rx, coefficients_kw, iterations, meta_lr=0.1, MAML=Tru
                the segment's iteration count, (n / 25) x (2e-5 + 1e-3 |w|).  Two fp32 implementations of ~200 chained Adam
                steps through ReLUs are not always one trajectory: a unit whose pre-activation crosses zero one iteration apart
                changes the gradient discretely (and exp_avg, a 10-iteration memory of the gradient, then differs by the size
-               of a gradient, which is why the moments are compared in the sharp check only).  Measured (242 segments of
-               configs[4]): 90 % of the segments end within 0.01 of their tolerance, a few meta-learning updates -- whose
-               inner SGD step of 0.1 makes every kink ten times closer -- end 10-70 x outside.  The caller asserts the
-               fraction of segments within tolerance; the ratios are returned.
+               of a gradient, which is why the moments are compared in the sharp check only).  Measured over the 242
+               segments of configs[4] (full-word iterations restarted from the saved weights, meta-learning updates with an
+               inner SGD step of 0.1): 219 end within their tolerance (186 within a tenth of it), 19 between 1 x and 3 x,
+               4 between 9 x and 67 x; all 278 minibatch segments of configs[2] end within 0.01 of theirs.  The caller
+               asserts the fraction of segments within tolerance; the ratios are returned.
     Returns (segments replayed, worst sharp ratio, list of whole-segment ratios, ser_by_word, Adam steps)."""
     T = rx.shape[1]
     det = _vnet_with(w0, T, dev)
@@ -205,4 +206,4 @@ def test_config4_meta_viterbinet_replayed_block_by_block(golden, dev):
           f"whole segments: median {np.median(whole):.4f}, within tolerance {np.mean(whole <= 1.0):.3f}, worst {whole.max():.1f}; "
           f"mean ser {ser.mean():.5f}")
     assert segs >= 200 and steps > 200 * 150
-    assert np.mean(whole <= 1.0) >= 0.85 and np.median(whole) <= 0.1  # (measured 0.93 / 0.003; see _replay on the outliers)
+    assert np.mean(whole <= 1.0) >= 0.85 and np.median(whole) <= 0.1  # (measured 0.905 / 0.003; see _replay on the outliers)
