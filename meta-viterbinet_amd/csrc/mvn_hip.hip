@@ -455,13 +455,21 @@ __global__ __launch_bounds__(64 * kCountWaves) void count_errors_kernel(const fl
         const float *dr = dec + r * dec_ld, *tr = tx + r * tx_ld;
         if ((((uintptr_t)dr | (uintptr_t)tr) & 15) == 0) {  // 16-B aligned rows: 4 symbols per load
             const int K4 = K >> 2;
-            const float4 *d4 = reinterpret_cast<const float4 *>(dr), *t4 = reinterpret_cast<const float4 *>(tr);
-            for (int k0 = 0; k0 < K4; k0 += 256) {  // 8 loads in flight per lane (a 1000-symbol row is one trip)
+            // Rows of 1000 symbols start 0 / 32 / 64 / 96 bytes into a 128-B line.  A wave's load instruction then ends inside
+            // a line and the next one starts in it, and the memory side saw that line requested twice (761 k read requests
+            // per launch for 625 k lines, profiles/traffic.json of round 2).  When both rows sit at the same offset the loads
+            // are issued from the line boundary below the row instead: every instruction covers whole lines, the lanes in
+            // front of the row are masked.
+            const int shift = (int)(((uintptr_t)dr & 127) >> 4);  // float4s between the line boundary and the row
+            const bool same = (((uintptr_t)dr ^ (uintptr_t)tr) & 127) == 0;
+            const int lo = same ? shift : 0, hi = lo + K4;
+            const float4 *d4 = reinterpret_cast<const float4 *>(dr) - lo, *t4 = reinterpret_cast<const float4 *>(tr) - lo;
+            for (int k0 = 0; k0 < hi; k0 += 256) {  // 8 loads in flight per lane (a 1000-symbol row is one trip)
                 float4 a[4], c[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = k0 + 64 * j + lane;
-                    const bool in = k < K4;
+                    const bool in = k >= lo && k < hi;
                     a[j] = in ? d4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
                     c[j] = in ? t4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
@@ -837,13 +845,14 @@ int launch_online_train(const mvn_train_trial_t &one, const mvn_train_trial_t *m
         });
     }
     // one workgroup per chunk and trial, never more workgroups in a launch than the device has CUs (all resident at once)
+    const size_t ws_floats_one = train_groups_workspace_bytes(S, groups) / sizeof(float);
     const int per_launch = many ? trials_per_launch(R, cus / groups) : 1;
     for (int r0 = 0; r0 < R; r0 += per_launch) {
         const int nr = std::min(per_launch, R - r0);
         float *wsr = (float *)workspace + (size_t)r0 * stride;
         hipError_t e = clear_group_syncs(wsr, stride, nr, st);
         if (e != hipSuccess) return (int)e;
-        const GroupLaunch gl = {wsr, (long long)stride, g_group_spin_limit, g_group_phantoms};
+        const GroupLaunch gl = {wsr, (long long)stride, (unsigned)((many ? stride : ws_floats_one) * sizeof(float)), g_group_spin_limit, g_group_phantoms};
         const int rc = dispatch_states(S, many != nullptr, [&](auto sc) -> int {
             constexpr int SC = decltype(sc)::value;
             if (many) {
@@ -889,13 +898,14 @@ int launch_maml_train(const mvn_train_trial_t &one, const mvn_train_trial_t *man
             return (int)hipGetLastError();
         });
     }
+    const size_t ws_floats_one = maml_groups_workspace_bytes(S, groups) / sizeof(float);
     const int per_launch = many ? trials_per_launch(R, cus / groups) : 1;
     for (int r0 = 0; r0 < R; r0 += per_launch) {
         const int nr = std::min(per_launch, R - r0);
         float *wsr = (float *)workspace + (size_t)r0 * stride;
         hipError_t e = clear_group_syncs(wsr, stride, nr, st);
         if (e != hipSuccess) return (int)e;
-        const GroupLaunch gl = {wsr, (long long)stride, g_group_spin_limit, g_group_phantoms};
+        const GroupLaunch gl = {wsr, (long long)stride, (unsigned)((many ? stride : ws_floats_one) * sizeof(float)), g_group_spin_limit, g_group_phantoms};
         const int rc = dispatch_states(S, many != nullptr, [&](auto sc) -> int {
             constexpr int SC = decltype(sc)::value;
             if (many) {
