@@ -289,7 +289,7 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
                 "cu_occupancy": per_launch * groups / n_cu.value, "workgroups_per_trial": groups, "trials_per_launch": per_launch,
                 "adam_steps": stats["adam_steps"], "algorithmic_flop": flop}
 
-    R2 = int(os.environ.get("MVN_BENCH_TRIALS_SELFSUP", "128"))
+    R2 = int(os.environ.get("MVN_BENCH_TRIALS_SELFSUP", "256"))  # one workgroup per trial: a trial per CU
     kw2 = dict(self_supervised=True, self_supervised_iterations=200)
     one_trial("cost2100", 0, 100, **kw2)  # warm
     ms2c1, _ = wall_ms(lambda: one_trial("cost2100", 0, 100, **kw2), dev)
@@ -326,7 +326,7 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
                         "the training launches, see self_supervised_trials.roofline"})
 
     # ---- configs[4]: Meta-ViterbiNet online retrain + decode, reference defaults (200 / 20 / 10 / 5), replicas
-    R4 = int(os.environ.get("MVN_BENCH_TRIALS_META", "56"))
+    R4 = int(os.environ.get("MVN_BENCH_TRIALS_META", "102"))  # 2 x 51 trials x 5 workgroups (online), 4 x 25-26 x 9 (meta-learning)
     kw4 = dict(self_supervised=True, self_supervised_iterations=200, online_meta=True, meta_train_iterations=20, meta_j_num=10,
                meta_subframes=5, meta_style_online_training=True)
     ms41, _ = wall_ms(lambda: one_trial("time_decay", 0, 200, **kw4), dev)

@@ -316,14 +316,16 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
                     for p_, w_ in zip(detector.parameters(), meta_training_weights):
                         p_.copy_(torch.as_tensor(w_, dtype=p_.dtype))
             if hip_meta:  # every MAML step of this update in ONE launch of the meta-learning kernel
-                sup, qry = [], []
-                for _ in range(meta_train_iterations):
-                    j_hat_values = draw_j_hat(buffer_rx.shape[0] - 2)
-                    sup.append(j_hat_values.reshape(-1, 1) + support_idx.reshape(1, -1) + 1)
-                    qry.append(j_hat_values + query_idx + 1)
-                online_trainer.maml_training(buffer_rx, buffer_tx, torch.cat(sup), torch.cat(qry), meta_lr, MAML)
+                if draws is not None:  # the update's j_hat values in one draw (this trial's own stream)
+                    j_all = torch.as_tensor(draws.j_hat_update(buffer_rx.shape[0] - 2, meta_train_iterations, meta_j_num),
+                                            device=rx.device).long()
+                else:
+                    j_all = torch.cat([draw_j_hat(buffer_rx.shape[0] - 2) for _ in range(meta_train_iterations)])
+                sup_all = j_all.reshape(-1, 1) + support_idx.reshape(1, -1) + 1
+                qry_all = j_all + query_idx + 1
+                online_trainer.maml_training(buffer_rx, buffer_tx, sup_all, qry_all, meta_lr, MAML)
                 if seen is not None:
-                    seen["meta"] = (torch.cat(sup), torch.cat(qry))
+                    seen["meta"] = (sup_all, qry_all)
             else:
                 if graphed_meta and meta_step is None:  # captured once: one hipGraph replay per MAML step from here on
                     meta_step = GraphedMetaStep(detector, meta_detector, online_trainer, window_size, rx.shape[1], meta_lr,

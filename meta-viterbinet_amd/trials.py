@@ -43,6 +43,13 @@ def beta_power(beta: float, step: int) -> float:
     return float(np.float32(beta)) ** int(step)
 
 
+def beta_powers(beta: float, steps) -> np.ndarray:
+    """beta_power for an array of step counts, one libm pow() each (a vectorised pow may round differently: the batched run
+    must hand its kernels the very doubles the single-trial entry points compute)."""
+    b = float(np.float32(beta))
+    return np.array([b ** int(s) for s in steps], dtype=np.float64)
+
+
 class TrialDraws:
     """The random draws of ONE trial's online training, a pure function of (seed, shapes): the minibatches of select_batch
     (trainer.py:534-544: torch.multinomial with weights arange(T), without replacement) for every (block, iteration), drawn
@@ -72,7 +79,15 @@ class TrialDraws:
 
     def j_hat(self, high: int, size: int) -> np.ndarray:
         """np.unique(randint(0, high, size)): sorted distinct buffer positions, like torch.unique(torch.randint(...))."""
-        return np.unique(self.rng.randint(0, high, size=size))
+        return self.j_hat_update(high, 1, size)
+
+    def j_hat_update(self, high: int, iterations: int, size: int) -> np.ndarray:
+        """The j_hat values of ONE meta-learning update, concatenated in step order: `iterations` times (trainer.py:335-338)
+        the sorted distinct values of `size` draws from [0, high).  One generator call and one sort for the whole update."""
+        x = np.sort(self.rng.randint(0, high, size=(iterations, size)), axis=1)
+        keep = np.ones(x.shape, dtype=bool)
+        keep[:, 1:] = x[:, 1:] != x[:, :-1]
+        return x[keep]  # row-major: iteration after iteration, ascending within each
 
 
 class TrialBank:
@@ -181,6 +196,8 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
             raise ValueError("weights_init='meta_training' needs meta_training_weights (six arrays in parameters() order)")
         init_bank = TrialBank([meta_training_weights], S, bank.memory_length, dev)
         init_p = np.repeat(init_bank.pointers(init_bank.theta), R, axis=0)
+    sup_off = np.arange(-W, 0)
+    table_p = None
     w_stride = (ctypes.c_int64 * 6)(*([bank.P] * 6))
     wp = [ctypes.c_void_p(bank.theta.data_ptr() + 4 * int(bank.off[a])) for a in range(6)]
     stream = _lib.current_stream(dev)
@@ -232,31 +249,29 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
                 if act:
                     words = idx.np.view(np.int32)
                     pos = 0
+                    offs, ns = np.empty(len(act), np.int64), np.empty(len(act), np.int32)
                     for k, r in enumerate(act):
-                        buf = np.asarray(buffers[r], dtype=np.int64)
-                        sup, qry = [], []
-                        for _ in range(meta_train_iterations):
-                            j_hat = draws[r].j_hat(len(buf) - 2, meta_j_num)
-                            # support j_hat + [-W .. -1], query j_hat: positions in the buffer, negative = from its end
-                            sup.append(buf[(j_hat[:, None] + np.arange(-W, 0)[None, :]) % len(buf)])
-                            qry.append(buf[j_hat])
-                        sup, qry = np.concatenate(sup).astype(np.int32), np.concatenate(qry).astype(np.int32)
-                        n = qry.shape[0]
-                        words[pos:pos + n * W] = sup.reshape(-1)
-                        words[pos + n * W:pos + n * (W + 1)] = qry
-                        d = d_meta[k]
-                        d["y"], d["labels"] = rx_p[r], lab_p[r]
-                        d["idx"] = np.uint64(idx.dev.data_ptr() + 4 * pos)
-                        d["query_idx"] = np.uint64(idx.dev.data_ptr() + 4 * (pos + n * W))
-                        d["w_in"] = saved_p[r] if weights_init == "last_frame" else init_p[r]
-                        d["w_out"], d["w_out2"] = theta_p[r], saved_p[r]
-                        d["adam_m"], d["adam_v"], d["loss_out"], d["status"] = m_p[r], v_p[r], 0, status_p[r]
-                        d["b1pow"], d["b2pow"] = beta_power(b1, bank.step[r]), beta_power(b2, bank.step[r])
-                        d["n"], d["reserved"] = n, 0
-                        bank.step[r] += n
+                        buf = np.asarray(buffers[r], dtype=np.int32)
+                        j_hat = draws[r].j_hat_update(len(buf) - 2, meta_train_iterations, meta_j_num)
+                        n = j_hat.shape[0]
+                        # support j_hat + [-W .. -1], query j_hat: positions in the buffer, negative = from its end
+                        words[pos:pos + n * W] = buf[(j_hat[:, None] + sup_off[None, :]) % len(buf)].reshape(-1)
+                        words[pos + n * W:pos + n * (W + 1)] = buf[j_hat]
+                        offs[k], ns[k] = pos, n
                         pos += n * (W + 1)
                         if record is not None:
                             record["meta"][r, count] = True
+                    a = np.asarray(act)
+                    d = d_meta[:len(act)]
+                    d["y"], d["labels"] = rx_p[a], lab_p[a]
+                    d["idx"] = np.uint64(idx.dev.data_ptr()) + (4 * offs).astype(np.uint64)
+                    d["query_idx"] = np.uint64(idx.dev.data_ptr()) + (4 * (offs + ns.astype(np.int64) * W)).astype(np.uint64)
+                    d["w_in"] = saved_p[a] if weights_init == "last_frame" else init_p[a]
+                    d["w_out"], d["w_out2"] = theta_p[a], saved_p[a]
+                    d["adam_m"], d["adam_v"], d["loss_out"], d["status"] = m_p[a], v_p[a], 0, status_p[a]
+                    d["b1pow"], d["b2pow"] = beta_powers(b1, bank.step[a]), beta_powers(b2, bank.step[a])
+                    d["n"], d["reserved"] = ns, 0
+                    bank.step[a] += ns
                     idx.send(4 * pos)
                     desc.send(len(act) * TRIAL_DTYPE.itemsize)
                     rc = lib.mvn_vnet_maml_train_trials_f32(desc_meta_ptr, len(act), T, W, meta_lr, 1 if MAML else 0, bank.lr,
@@ -266,22 +281,23 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
             if self_supervised and push.any():
                 act = np.flatnonzero(push)
                 if M and tables is None:
-                    tables = [draws[r].batches(0, N, T, self_supervised_iterations, M) for r in range(R)]  # draws the tables
+                    for r in range(R):
+                        draws[r].batches(0, N, T, self_supervised_iterations, M)  # draws the trial's table
                     tables = [draws[r]._table for r in range(R)]
-                for k, r in enumerate(act):
-                    d = d_onl[k]
-                    d["y"] = rx_p[r] + np.uint64(4 * count * T)
-                    d["labels"] = lab_p[r] + np.uint64(4 * count * T)
-                    d["idx"] = np.uint64(tables[r].data_ptr() + 4 * count * self_supervised_iterations * M) if M else 0
-                    d["query_idx"] = 0
-                    d["w_in"] = saved_p[r] if meta_style_online_training else theta_p[r]  # metavnet_trainer.py:59
-                    d["w_out"], d["w_out2"] = theta_p[r], 0
-                    d["adam_m"], d["adam_v"], d["loss_out"], d["status"] = m_p[r], v_p[r], 0, status_p[r]
-                    d["b1pow"], d["b2pow"] = beta_power(b1, bank.step[r]), beta_power(b2, bank.step[r])
-                    d["n"], d["reserved"] = self_supervised_iterations, 0
-                    bank.step[r] += self_supervised_iterations
-                    if record is not None:
-                        record["trained"][r, count] = True
+                    table_p = np.array([t.data_ptr() for t in tables], dtype=np.uint64)
+                d = d_onl[:len(act)]
+                d["y"] = rx_p[act] + np.uint64(4 * count * T)
+                d["labels"] = lab_p[act] + np.uint64(4 * count * T)
+                d["idx"] = table_p[act] + np.uint64(4 * count * self_supervised_iterations * M) if M else 0
+                d["query_idx"] = 0
+                d["w_in"] = saved_p[act] if meta_style_online_training else theta_p[act]  # metavnet_trainer.py:59
+                d["w_out"], d["w_out2"] = theta_p[act], 0
+                d["adam_m"], d["adam_v"], d["loss_out"], d["status"] = m_p[act], v_p[act], 0, status_p[act]
+                d["b1pow"], d["b2pow"] = beta_powers(b1, bank.step[act]), beta_powers(b2, bank.step[act])
+                d["n"], d["reserved"] = self_supervised_iterations, 0
+                bank.step[act] += self_supervised_iterations
+                if record is not None:
+                    record["trained"][act, count] = True
                 off = R * TRIAL_DTYPE.itemsize
                 desc.dev[off:off + len(act) * TRIAL_DTYPE.itemsize].copy_(desc.host[off:off + len(act) * TRIAL_DTYPE.itemsize],
                                                                           non_blocking=True)
