@@ -230,7 +230,8 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
             nerr = torch.zeros(N, dtype=torch.int32, device=rx.device)
             for count in range(N):
                 if count % subframes_in_frame != 0:
-                    _byword_step(detector, rx[count:count + 1], tx[count:count + 1], n_symbols, False, nerr[count:count + 1])
+                    _byword_step(detector, rx[count:count + 1], tx[count:count + 1], n_symbols, False, nerr[count:count + 1],
+                                 outputs=False)
             e = nerr.cpu().numpy()
             data = np.arange(N) % subframes_in_frame != 0
             ser_by_word[data] = _metrics.ser_from_errors(e[data], K)  # the reference's value bit for bit (metrics.py:13-16)
@@ -376,18 +377,18 @@ def _fused_step_applies(detector, rx: torch.Tensor, n_symbols: int, pass_count: 
 
 
 def _byword_step(detector, received_word: torch.Tensor, transmitted_word: torch.Tensor, n_symbols: int, pilot: bool,
-                 nerr: torch.Tensor):
+                 nerr: torch.Tensor, outputs: bool = True):
     """One block of eval_by_word in one launch (trainer.py:292-316): returns (detected_word, encoded_word) [1, T]; the
     block's bit-error count goes to nerr[0] (device int32).  On a pilot the detection is skipped (never used) and
-    detected_word is None."""
+    detected_word is None.  outputs=False: the error count only (no words are stored, the re-encoding is skipped)."""
     from . import _lib
 
     rxw, txw = _lib.f32c(received_word), _lib.f32c(transmitted_word)
     T, K = rxw.shape[1], txw.shape[1]
     dev = rxw.device
     w = detector._params()
-    det = None if pilot else torch.empty((1, T), dtype=torch.float32, device=dev)
-    enc = torch.empty((1, T), dtype=torch.float32, device=dev)
+    det = None if (pilot or not outputs) else torch.empty((1, T), dtype=torch.float32, device=dev)
+    enc = torch.empty((1, T), dtype=torch.float32, device=dev) if outputs else None
     with _lib.on_device(dev):
         rc = _lib.load().mvn_vnet_byword_step_f32(_lib.ptr(rxw), T, _lib.ptr(txw), K, *[_lib.ptr(_lib.f32c(p)) for p in w], None,
                                                   _lib.ptr(det), T, None, K, _lib.ptr(enc), T, None, T, None, T,

@@ -11,7 +11,7 @@ mkdir -p "$R/$OUT"
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES"; do
   tag=$(echo $C | tr ' ' '_')
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$R/$OUT/$tag" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --skip-fused-count > /dev/null 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$R/$OUT/$tag" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-sustained --skip-fused-count > /dev/null 2>&1
 done
 python3 "$R/tools/pmc_summarize.py" "$R/$OUT" > "$R/$OUT/summary.csv"
 python3 "$R/tools/pmc_to_traffic_json.py" "$R/$OUT/summary.csv" "$R/$OUT"

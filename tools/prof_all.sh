@@ -1,0 +1,23 @@
+set -e
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r03p
+mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+echo bench done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o t -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-sustained > /dev/null 2>&1
+python3 $R/tools/stats_by_grid.py $O/kt/t_kernel_trace.csv > $O/kernel_durations_by_grid.csv
+cp $O/kt/t_kernel_stats.csv $O/kernel_stats.csv
+echo kt done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kh -o t -- python3 $R/bench.py --no-cpu-baseline --no-configs --skip-fused-count --no-sustained > /dev/null 2>&1
+cp $O/kh/t_kernel_stats.csv $O/headline_kernel_stats.csv
+python3 $R/tools/stats_by_grid.py $O/kh/t_kernel_trace.csv > $O/headline_by_grid.csv
+echo kh done
+cd $R && bash tools/pmc_traffic.sh gpurun_out/r03p/pmc > $O/pmc.log 2>&1
+echo pmc done
+python3 tools/time_trials.py 1 16 28 51 102 256 2>&1 | grep -v amdgpu.ids > $O/time_trials.txt
+python3 tools/time_step.py 2>&1 | grep -v amdgpu.ids > $O/time_step.txt
+python3 tools/time_online.py 2>&1 | grep -v amdgpu.ids > $O/time_online_training.txt
+timeout -k 10 200 python3 tools/fuzz_parity.py 120 2>&1 | grep -v amdgpu.ids | tail -5 > $O/fuzz_parity.txt
+rm -rf $O/kt $O/kh $O/pmc/FETCH_SIZE $O/pmc/WRITE_SIZE $O/pmc/TCC* $O/pmc/SQ*
+ls $O $O/pmc
