@@ -197,3 +197,36 @@ def test_optimizer_variants_match_torch_optim(opt):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
     with pytest.raises(NotImplementedError):
         mvn.OnlineTrainer(det, 4, optimizer_type="Adagrad")
+
+
+def test_trial_draws_and_descriptor_helpers():
+    """Host side of trials.eval_by_word_batched (no GPU): a trial's draws are a pure function of its seed -- the meta-learning
+    update's j_hat values drawn in one call equal the reference's per-iteration torch.unique(randint) pattern on the same
+    stream --, beta powers are libm pow of the float-rounded beta like the C entry points compute them, and the flat
+    parameter layout is parameters() order."""
+    from meta_viterbinet_amd import trials
+
+    a, b = trials.TrialDraws(7, "cpu"), trials.TrialDraws(7, "cpu")
+    one = a.j_hat_update(37, 20, 10)
+    per_iteration = np.concatenate([np.unique(b.rng.randint(0, 37, size=10)) for _ in range(20)])
+    assert np.array_equal(one, per_iteration) and one.min() >= 0 and one.max() < 37
+    assert not np.array_equal(one, trials.TrialDraws(8, "cpu").j_hat_update(37, 20, 10))
+    t1 = trials.TrialDraws(3, "cpu").batches(4, 6, 40, 5, 8)
+    t2 = trials.TrialDraws(3, "cpu").batches(4, 6, 40, 5, 8)
+    assert t1.shape == (5, 8) and t1.dtype == torch.int32 and torch.equal(t1, t2)
+    assert int(t1.min()) >= 1 and int(t1.max()) < 40  # select_batch's weights arange(T): sample 0 is never drawn
+    assert all(len(set(row.tolist())) == 8 for row in t1)  # without replacement
+    with pytest.raises(ValueError):
+        a.batches(0, 6, 40, 5, 8)
+        a.batches(0, 7, 40, 5, 8)  # a trial's table is drawn once, for one shape
+    steps = np.array([0, 1, 200, 15315], dtype=np.int64)
+    want = [float(np.float32(0.999)) ** int(s) for s in steps]
+    assert trials.beta_powers(0.999, steps).tolist() == want and trials.beta_power(0.999, 200) == want[2]
+    off = trials.param_offsets(16)
+    assert off.tolist() == [0, 100, 200, 5200, 5250, 6050, 6066]
+    det = mvn.VNETDetector(16, {"train": 8, "val": 8}).to("cpu")
+    assert sum(p.numel() for p in det.parameters()) == off[-1]
+    assert [p.numel() for p in det.parameters()] == np.diff(off).tolist()
+    assert trials.TRIAL_DTYPE.itemsize == 232
+    # the reference's per-block ser from an error count (metrics.py:11-16), vectorised
+    assert mvn.metrics.ser_from_errors(np.array([0, 3, 120]), 120).tolist() == [0.0, 1.0 - float(np.float32(117) / np.float32(120)), 1.0]
