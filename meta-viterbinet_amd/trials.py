@@ -143,17 +143,69 @@ class _Staging:
         self.dev[:nbytes].copy_(self.host[:nbytes], non_blocking=True)
 
 
+class _BankRows:
+    """Rows [lo, hi) of a TrialBank: the same attributes, as views."""
+
+    def __init__(self, bank: TrialBank, lo: int, hi: int):
+        self.R = hi - lo
+        self.n_states, self.memory_length, self.lr, self.betas, self.eps = bank.n_states, bank.memory_length, bank.lr, bank.betas, bank.eps
+        self.off, self.P = bank.off, bank.P
+        self.theta, self.saved = bank.theta[lo:hi], bank.saved[lo:hi]
+        self.exp_avg, self.exp_avg_sq = bank.exp_avg[lo:hi], bank.exp_avg_sq[lo:hi]
+        self.step = bank.step[lo:hi]
+
+    pointers = TrialBank.pointers
+
+
 def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_symbols: int, subframes_in_frame: int,
                          draws: Sequence[TrialDraws], self_supervised: bool = False, self_supervised_iterations: int = 200,
                          ser_thresh: float = 0.02, online_meta: bool = False, meta_lr: float = 0.1, MAML: bool = True,
                          window_size: int = 1, meta_train_iterations: int = 20, meta_j_num: int = 10, meta_subframes: int = 5,
                          meta_style_online_training: bool = False, train_minibatch_size: int = 32,
-                         weights_init: str = "last_frame", meta_training_weights=None, record: Optional[dict] = None) -> np.ndarray:
+                         weights_init: str = "last_frame", meta_training_weights=None, record: Optional[dict] = None,
+                         cohorts: int = 1) -> np.ndarray:
     """R trials of harness.eval_by_word (= Trainer.eval_by_word, trainer.py:267-354, buffer_empty=True, Adam) at once.
     tx [R, N, K] message bits, rx [R, N, K + 8 n_symbols] received words (trial r = row r, its own SNR / channel / seed);
     bank: the trials' weights and optimizer state (updated in place); draws[r]: trial r's TrialDraws.
     Returns ser_by_word [R, N] (0 for pilots), row r equal to eval_by_word(..., draws=draws[r]) run alone.
-    record: optional dict that receives 'nerr' [R, N], 'trained' [R, N] bool and 'meta' [R, N] bool."""
+    record: optional dict that receives 'nerr' [R, N], 'trained' [R, N] bool and 'meta' [R, N] bool.
+    cohorts > 1: the trials are split into that many groups that step ALTERNATELY on the same stream: while the GPU works
+    through one group's training launches the host takes the decisions and fills the descriptors of the next (the host
+    work of a step can only start after the step's sync).  Same launches per trial, same results."""
+    R, N = rx.shape[0], rx.shape[1]
+    if R != bank.R or len(draws) != R or tx.shape[0] != R:
+        raise ValueError("tx [R, N, K], rx [R, N, K + 8 n_symbols], one TrialDraws and one bank row per trial")
+    ser_by_word = np.zeros((R, N))
+    if record is not None:
+        record.update(nerr=np.zeros((R, N), np.int64), trained=np.zeros((R, N), bool), meta=np.zeros((R, N), bool))
+    cohorts = max(1, min(int(cohorts), R))
+    bounds = [(c * R) // cohorts for c in range(cohorts + 1)]
+    gens = []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        rec = None if record is None else {k: record[k][lo:hi] for k in ("nerr", "trained", "meta")}
+        gens.append(_cohort_steps(_BankRows(bank, lo, hi), tx[lo:hi], rx[lo:hi], n_symbols, subframes_in_frame, draws[lo:hi],
+                                  ser_by_word[lo:hi], rec, self_supervised, self_supervised_iterations, ser_thresh, online_meta,
+                                  meta_lr, MAML, window_size, meta_train_iterations, meta_j_num, meta_subframes,
+                                  meta_style_online_training, train_minibatch_size, weights_init, meta_training_weights))
+    with _lib.on_device(rx.device):
+        waiting = [next(g) for g in gens]  # every cohort has enqueued its first step and says which event ends it
+        while gens:
+            for i in range(len(gens)):  # round-robin: wait for cohort i's step, decide and enqueue, move on
+                waiting[i].synchronize()
+                try:
+                    waiting[i] = next(gens[i])
+                except StopIteration:
+                    gens[i] = None
+            waiting = [w for w, g in zip(waiting, gens) if g is not None]
+            gens = [g for g in gens if g is not None]
+    return ser_by_word
+
+
+def _cohort_steps(bank, tx, rx, n_symbols, subframes_in_frame, draws, ser_by_word, record, self_supervised,
+                  self_supervised_iterations, ser_thresh, online_meta, meta_lr, MAML, window_size, meta_train_iterations, meta_j_num,
+                  meta_subframes, meta_style_online_training, train_minibatch_size, weights_init, meta_training_weights):
+    """One group of trials stepping through its blocks: a generator that enqueues a step's GPU work and yields the event the
+    host has to wait for before it can decide what the trials do next (eval_by_word_batched drives one or more of these)."""
     if bank.n_states != 16:
         raise NotImplementedError("the batched evaluation runs the 16-state kernels (mvn_vnet_byword_step_f32)")
     if weights_init not in ("last_frame", "meta_training"):
@@ -203,21 +255,11 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
     stream = _lib.current_stream(dev)
     ts = torch.cuda.current_stream(dev)
 
-    ser_by_word = np.zeros((R, N))
     buffers: List[List[int]] = [[] for _ in range(R)]  # trial r's buffer: the block numbers it holds, oldest first
-    if record is not None:
-        record.update(nerr=np.zeros((R, N), np.int64), trained=np.zeros((R, N), bool), meta=np.zeros((R, N), bool))
     tables = None
-    timing = None
-    if record is not None and record.get("timing"):
-        import time
-
-        timing = record["timing"] = {"wait": 0.0, "host": 0.0}
-        t_c = time.perf_counter()
-    with _lib.on_device(dev):
+    done = torch.cuda.Event()
+    if True:  # (the driver holds the device guard)
         for count in range(N):
-            if timing is not None and count:
-                t_c = t_b
             pilot = 1 if count % subframes_in_frame == 0 else 0
             rc = lib.mvn_vnet_byword_step_f32(ctypes.c_void_p(rx.data_ptr() + 4 * count * T), N * T,
                                               ctypes.c_void_p(tx.data_ptr() + 4 * count * K), N * K, *wp, w_stride,
@@ -226,13 +268,8 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
                                               ctypes.c_void_p(sync_dev.data_ptr()), R, T, n_symbols, pilot, S, stream)
             _lib.check(rc, "mvn_vnet_byword_step_f32")
             sync_host.copy_(sync_dev, non_blocking=True)
-            if timing is not None:
-                t_a = time.perf_counter()
-            ts.synchronize()  # the one host sync of the step (the reference has one per trial and block, trainer.py:305)
-            if timing is not None:
-                t_b = time.perf_counter()
-                timing["wait"] += t_b - t_a
-                timing["host"] += t_a - t_c
+            done.record(ts)
+            yield done  # the one host sync of the step (the reference has one per trial and block, trainer.py:305)
             if status_np.any():
                 raise _lib.MvnError(f"trials {np.flatnonzero(status_np).tolist()}: {lib.mvn_strerror(-7).decode()}")
             ser = ser_from_errors(nerr_np, K)  # the reference's value bit for bit (metrics.py:13-16)
@@ -305,7 +342,7 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
                                                           _lib.ptr(ws), ws_bytes, stream)
                 _lib.check(rc, "mvn_vnet_online_train_trials_f32")
         sync_host.copy_(sync_dev, non_blocking=True)
-        ts.synchronize()
+        done.record(ts)
+        yield done
         if status_np.any():
             raise _lib.MvnError(f"trials {np.flatnonzero(status_np).tolist()}: {lib.mvn_strerror(-7).decode()}")
-    return ser_by_word

@@ -164,6 +164,11 @@ def test_batched_trials_equal_sequential_runs(golden, dev, flow):
     bank = TrialBank(w, 16, 4, dev)
     rec = {}
     ser_b = eval_by_word_batched(bank, msg, rx, nsym, sub, [TrialDraws(100 + r, dev) for r in range(R)], record=rec, **kw)
+    # the same trials as three cohorts stepping alternately on one stream (host work of one behind the GPU work of another)
+    bank3 = TrialBank(w, 16, 4, dev)
+    ser_3 = eval_by_word_batched(bank3, msg, rx, nsym, sub, [TrialDraws(100 + r, dev) for r in range(R)], cohorts=3, **kw)
+    assert np.array_equal(ser_3, ser_b) and torch.equal(bank3.theta, bank.theta) and torch.equal(bank3.exp_avg_sq, bank.exp_avg_sq)
+    assert np.array_equal(bank3.step, bank.step)
     trained_blocks = 0
     for r in range(R):
         det = _vnet_with(w[r], K + 8 * nsym, dev)

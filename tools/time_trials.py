@@ -34,6 +34,7 @@ FLOWS = {"configs[2] self-supervised (200 minibatch iterations / block)": ("cost
          "configs[4] Meta-ViterbiNet (200 / 20 / 10 / 5)": ("time_decay", dict(self_supervised=True, self_supervised_iterations=200, online_meta=True,
                                                                 meta_train_iterations=20, meta_j_num=10, meta_subframes=5,
                                                                 meta_style_online_training=True))}
+COHORTS = int(os.environ.get("MVN_TRIAL_COHORTS", "1"))
 Rs = [int(a) for a in sys.argv[1:]] or [1, 8, 16, 28, 32, 64]
 for name, (coef, kw) in FLOWS.items():
     print(name)
@@ -63,7 +64,7 @@ for name, (coef, kw) in FLOWS.items():
                     d.batches(0, N, T, 200, 32)  # the draw tables are inputs, like the words
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            ser = eval_by_word_batched(bank, msg, rx, nsym, sub, draws, **kw)
+            ser = eval_by_word_batched(bank, msg, rx, nsym, sub, draws, cohorts=COHORTS, **kw)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-        print(f"  batched, R = {R:3d}     : {dt * 1e3:8.1f} ms  {R * N / dt:9.0f} blocks/s  mean ser {ser.mean():.5f}  steps {int(bank.step.sum())}")
+        print(f"  batched, R = {R:3d}{' x%d cohorts' % COHORTS if COHORTS > 1 else ''}     : {dt * 1e3:8.1f} ms  {R * N / dt:9.0f} blocks/s  mean ser {ser.mean():.5f}  steps {int(bank.step.sum())}")
