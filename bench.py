@@ -284,7 +284,12 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
         maml_steps = stats["adam_steps"] - online_steps
         flop = 35e3 * samples * online_steps + (35e3 * 2 * T2 + 105e3 * T2) * maml_steps
         ach = flop / (stats["ms"] * 1e-3) / 1e12
-        per_launch = min(trials, max(1, n_cu.value // groups))
+        # the library's own choice (mvn_hip.hip: one_workgroup_per_trial_is_faster): chunked passes finish a trial soonest, one
+        # workgroup per trial gets the most trials through a CU per second
+        fit = max(1, n_cu.value // groups)
+        if groups > 1 and (4.0 if maml else 3.3) * -(-trials // n_cu.value) < -(-trials // fit):
+            groups, fit = 1, n_cu.value
+        per_launch = min(trials, fit)
         return {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                 "cu_occupancy": per_launch * groups / n_cu.value, "workgroups_per_trial": groups, "trials_per_launch": per_launch,
                 "adam_steps": stats["adam_steps"], "algorithmic_flop": flop}
@@ -326,7 +331,7 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
                         "the training launches, see self_supervised_trials.roofline"})
 
     # ---- configs[4]: Meta-ViterbiNet online retrain + decode, reference defaults (200 / 20 / 10 / 5), replicas
-    R4 = int(os.environ.get("MVN_BENCH_TRIALS_META", "102"))  # 2 x 51 trials x 5 workgroups (online), 4 x 25-26 x 9 (meta-learning)
+    R4 = int(os.environ.get("MVN_BENCH_TRIALS_META", "256"))  # a trial per CU: the library then runs one workgroup per trial
     kw4 = dict(self_supervised=True, self_supervised_iterations=200, online_meta=True, meta_train_iterations=20, meta_j_num=10,
                meta_subframes=5, meta_style_online_training=True)
     ms41, _ = wall_ms(lambda: one_trial("time_decay", 0, 200, **kw4), dev)
@@ -341,11 +346,12 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
                 "one_trial": {"ms": ms41, "ms_per_block": ms41 / N, "blocks_per_s": N / (ms41 * 1e-3)},
                 "speedup_vs_one_trial_at_a_time": (R4 * N / ms4) / (N / ms41),
                 "mean_ser_by_snr_db": {str(7 + k): float(np.nanmean(rep4[k::6])) for k in range(6)},
-                "kernel": "maml_train_groups_kernel + online_train_groups_kernel + byword_step_kernel",
+                "kernel": "maml_train(_groups)_kernel + online_train(_groups)_kernel + byword_step_kernel",
                 "what": f"{R4} independent trial(s) per GPU stepping together (replicas: block k's weights depend on the blocks before it); "
                         "per block step one byword_step_kernel launch, one host sync, and for the trials that train one launch sequence of "
-                        "maml_train_groups_kernel (9 workgroups per trial) and online_train_groups_kernel (5 per trial), never more "
-                        "workgroups per launch than CUs; one all_gather of ser_by_word[300] per trial",
+                        "the meta-learning and the online-training kernel (gridDim.y = trial): one workgroup per 32-sample chunk and trial "
+                        "(9 / 5 workgroups, never more per launch than CUs) for few trials, one workgroup per trial from ~130-200 trials on "
+                        "(more trials through a CU per second; same bits); one all_gather of ser_by_word[300] per trial",
                 "roofline": training_roofline(st4, R4, 200, T2, True, 9),
                 "note": "training passes run one workgroup per 32-sample chunk and trial, gradients exchanged through a per-trial workspace "
                         "with one device-wide barrier per pass (DESIGN.md 5.6, 5.7)"})

@@ -805,6 +805,19 @@ int trials_per_launch(int R, int fit) {
     return (R + launches - 1) / launches;
 }
 
+// Many trials: one workgroup per CHUNK and trial finishes a trial soonest, one workgroup per TRIAL gets the most trials through
+// a CU per second (no exchange, no workgroup waiting for a pass it has no chunk of): a full-word iteration costs 10.6 us on 5
+// CUs or 34.7 us on one, a second-order meta-learning step 38 us on 9 or 154 us on one (first order 24 / 72;
+// profiles/r0{2,3}_time_online_training.txt).  With R trials the chunked form needs ceil(R / (CUs / groups)) launches one after
+// the other, the one-workgroup form ceil(R / CUs) rounds of `slowdown` times the length: take whichever ends first.  (Both
+// forms give the same bits.)
+bool one_workgroup_per_trial_is_faster(int R, int groups, int cus, double slowdown) {
+    if (groups < 2 || cus < groups) return true;
+    const int fit = cus / groups;
+    const double chunked = (double)((R + fit - 1) / fit), single = slowdown * (double)((R + cus - 1) / cus);
+    return single < chunked;
+}
+
 // zero the GroupSync at the head of each of `trials` workspace regions
 hipError_t clear_group_syncs(float *workspace, size_t stride_floats, int trials, hipStream_t st) {
     if (trials == 1) return hipMemsetAsync(workspace, 0, sizeof(GroupSync), st);
@@ -826,7 +839,8 @@ int launch_online_train(const mvn_train_trial_t &one, const mvn_train_trial_t *m
     const int cus = current_device_cus();
     const size_t stride = groups >= 2 ? trial_workspace_floats(S, groups) : 0;
     if (groups < 2 || !workspace || sw(SW_TRAIN_GROUPS) == '0' || groups > cus ||
-        workspace_bytes < (many ? (size_t)R * stride * sizeof(float) : train_groups_workspace_bytes(S, groups)))
+        workspace_bytes < (many ? (size_t)R * stride * sizeof(float) : train_groups_workspace_bytes(S, groups)) ||
+        (many && sw(SW_TRAIN_GROUPS) != '1' && one_workgroup_per_trial_is_faster(R, groups, cus, 3.3)))
         groups = 0;
     if (groups && (reinterpret_cast<uintptr_t>(workspace) & 15)) return MVN_E_WORKSPACE;
     if (!groups) {  // one workgroup per trial
@@ -880,7 +894,8 @@ int launch_maml_train(const mvn_train_trial_t &one, const mvn_train_trial_t *man
     const int cus = current_device_cus();
     const size_t stride = groups >= 2 ? trial_workspace_floats(S, groups) : 0;
     if (groups < 2 || !workspace || sw(SW_TRAIN_GROUPS) == '0' || groups > cus ||
-        workspace_bytes < (many ? (size_t)R * stride * sizeof(float) : maml_groups_workspace_bytes(S, groups)))
+        workspace_bytes < (many ? (size_t)R * stride * sizeof(float) : maml_groups_workspace_bytes(S, groups)) ||
+        (many && sw(SW_TRAIN_GROUPS) != '1' && one_workgroup_per_trial_is_faster(R, groups, cus, second_order ? 4.0 : 3.0)))
         groups = 0;
     if (groups && (reinterpret_cast<uintptr_t>(workspace) & 15)) return MVN_E_WORKSPACE;
     if (!groups) {
