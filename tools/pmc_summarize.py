@@ -4,8 +4,10 @@
 bench.py launches some kernels at several sizes (count_errors_kernel: 10 000-row headline steps, a 100-row and a 125 000-row
 config; the guard kernel; ...).  A mean over ALL dispatches of a name is a mean over different workloads -- round 2's
 "count_errors_kernel reads 98.5 MB for 80 MB" was exactly that: 45 headline dispatches of 625 k requests averaged with one
-125 000-row dispatch of 7.8 M.  So the mean is taken over the dispatches of the kernel's MOST FREQUENT grid size (the headline
-workload for every kernel of the headline step; the only size for the others), and the grid is printed."""
+125 000-row dispatch of 7.8 M.  So the figure reported per kernel is the MEDIAN over the dispatches of its most frequent grid
+size (count_errors_kernel caps its grid at 512 workgroups, so the grid alone does not tell its workloads apart): the headline
+workload for every kernel of the headline step, the only workload for the others.  The column keeps its name
+(`mean_per_dispatch`: the tools downstream read it); the plain mean is printed next to it."""
 import collections
 import csv
 import glob
@@ -27,10 +29,11 @@ for f in glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursi
                     short = short[:i]
                     break
             agg[short][int(r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-print("kernel,counter,mean_per_dispatch,dispatches,grid_threads,other_grids")
+print("kernel,counter,mean_per_dispatch,dispatches,grid_threads,other_grids,plain_mean")
 for k in sorted(agg):
     grids = agg[k]
     main = max(grids, key=lambda g: max(len(v) for v in grids[g].values()))
     for c in sorted(grids[main]):
-        v = grids[main][c]
-        print(f"\"{k}\",{c},{sum(v)/len(v):.1f},{len(v)},{main},{len(grids) - 1}")
+        v = sorted(grids[main][c])
+        med = v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+        print(f"\"{k}\",{c},{med:.1f},{len(v)},{main},{len(grids) - 1},{sum(v)/len(v):.1f}")

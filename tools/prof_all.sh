@@ -15,7 +15,7 @@ python3 $R/tools/stats_by_grid.py $O/kh/t_kernel_trace.csv > $O/headline_by_grid
 echo kh done
 cd $R && bash tools/pmc_traffic.sh gpurun_out/r03p/pmc > $O/pmc.log 2>&1
 echo pmc done
-python3 tools/time_trials.py 1 16 28 51 102 256 2>&1 | grep -v amdgpu.ids > $O/time_trials.txt
+python3 tools/time_trials.py 1 16 28 51 102 128 204 256 512 2>&1 | grep -v amdgpu.ids > $O/time_trials.txt
 python3 tools/time_step.py 2>&1 | grep -v amdgpu.ids > $O/time_step.txt
 python3 tools/time_online.py 2>&1 | grep -v amdgpu.ids > $O/time_online_training.txt
 timeout -k 10 200 python3 tools/fuzz_parity.py 120 2>&1 | grep -v amdgpu.ids | tail -5 > $O/fuzz_parity.txt
