@@ -270,3 +270,87 @@ def test_two_training_launches_in_flight(golden, dev):
     for a, b in zip(serial, overlapped):
         assert torch.equal(a, b)
     assert all(bool(torch.isfinite(a).all()) for a in serial)
+
+
+@pytest.mark.parametrize("S,T", [(4, 100), (32, 136), (8, 40)])
+def test_trial_entry_points_for_other_state_counts(dev, S, T):
+    """mvn_vnet_online_train_trials_f32 / mvn_vnet_maml_train_trials_f32 through hand-filled descriptors (what a C caller
+    does) for S != 16 -- the run-time-S instantiations of the trial kernels -- with trials of different iteration counts,
+    one inactive trial, separate input / output / second-copy weights: per trial bit-identical to mvn.OnlineTrainer (the
+    single-trial entry points), minibatch and full-word iterations, second-order meta-learning steps."""
+    from meta_viterbinet_amd import trials as tr_mod
+
+    lib, L, R = mvn._lib.load(), int(np.log2(S)), 4
+    rng = np.random.RandomState(S)
+    gen = torch.Generator(device=dev).manual_seed(S)
+
+    def rand_w():
+        return [(rng.uniform(-1, 1, (100, 1))).astype(np.float32), rng.uniform(-1, 1, 100).astype(np.float32),
+                rng.uniform(-0.1, 0.1, (50, 100)).astype(np.float32), rng.uniform(-0.1, 0.1, 50).astype(np.float32),
+                rng.uniform(-0.14, 0.14, (S, 50)).astype(np.float32), rng.uniform(-0.14, 0.14, S).astype(np.float32)]
+
+    ws = [rand_w() for _ in range(R)]
+    rxw = torch.randn(R, 6, T, generator=gen, device=dev)
+    txw = torch.randint(0, 2, (R, 6, T), generator=gen, device=dev).float()
+    labels = torch.stack([mvn.calculate_states(L, txw[r]).reshape(6, T) for r in range(R)]).to(torch.int32).contiguous()
+    n_iter = [7, 0, 12, 5]  # trial 1 is skipped
+    bidx = torch.stack([torch.stack([torch.randperm(T - 1, generator=gen, device=dev)[:32] + 1 for _ in range(12)]) for _ in range(R)]).to(torch.int32)
+    n_steps = [3, 5, 0, 4]
+    sup = torch.randint(0, 6, (R, 5, 1), generator=gen, device=dev).to(torch.int32)
+    qry = torch.randint(0, 6, (R, 5), generator=gen, device=dev).to(torch.int32)
+    for mode in ("minibatch", "full_word", "maml"):
+        bank = tr_mod.TrialBank(ws, S, L, dev)
+        bank.exp_avg.normal_(0, 1e-3, generator=gen)  # a carried-over optimizer state, different per trial
+        bank.exp_avg_sq.uniform_(1e-8, 1e-5, generator=gen)
+        bank.step[:] = [0, 3, 200, 41]
+        m0, v0, step0 = bank.exp_avg.clone(), bank.exp_avg_sq.clone(), bank.step.copy()
+        out2 = torch.zeros_like(bank.theta)
+        d = np.zeros(R, dtype=tr_mod.TRIAL_DTYPE)
+        th, sv = bank.pointers(bank.theta), bank.pointers(bank.saved)
+        o2 = bank.pointers(out2)
+        status = torch.zeros(R, dtype=torch.int32, device=dev)
+        for r in range(R):
+            n = n_steps[r] if mode == "maml" else n_iter[r]
+            d[r]["y"] = rxw[r].data_ptr() if mode == "maml" else rxw[r, 2].data_ptr()
+            d[r]["labels"] = labels[r].data_ptr() if mode == "maml" else labels[r, 2].data_ptr()
+            d[r]["idx"] = sup[r].data_ptr() if mode == "maml" else (bidx[r].data_ptr() if mode == "minibatch" else 0)
+            d[r]["query_idx"] = qry[r].data_ptr() if mode == "maml" else 0
+            d[r]["w_in"], d[r]["w_out"], d[r]["w_out2"] = sv[r], th[r], o2[r]  # read the saved copy, write two others
+            d[r]["adam_m"], d[r]["adam_v"] = bank.exp_avg[r].data_ptr(), bank.exp_avg_sq[r].data_ptr()
+            d[r]["status"] = status[r].data_ptr()
+            d[r]["b1pow"], d[r]["b2pow"] = tr_mod.beta_power(0.9, step0[r]), tr_mod.beta_power(0.999, step0[r])
+            d[r]["n"] = n
+        dd = torch.from_numpy(d.view(np.uint8)).to(dev)
+        nb = int(lib.mvn_vnet_train_trials_workspace_bytes(S, T, 1, R))
+        wsb = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+        if mode == "maml":
+            rc = lib.mvn_vnet_maml_train_trials_f32(mvn._lib.ptr(dd), R, T, 1, 0.1, 1, 1e-3, 0.9, 0.999, 1e-8, S, mvn._lib.ptr(wsb), nb,
+                                                    mvn._lib.current_stream(dev))
+        else:
+            rc = lib.mvn_vnet_online_train_trials_f32(mvn._lib.ptr(dd), R, T, 32 if mode == "minibatch" else 0, 1e-3, 0.9, 0.999, 1e-8, S,
+                                                      mvn._lib.ptr(wsb), nb, mvn._lib.current_stream(dev))
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert int(status.abs().sum()) == 0
+        for r in range(R):
+            n = n_steps[r] if mode == "maml" else n_iter[r]
+            if n == 0:  # untouched: weights, moments, second copy
+                assert torch.equal(bank.theta[r], bank.saved[r]) and torch.equal(bank.exp_avg[r], m0[r]) and not bool(out2[r].any())
+                continue
+            det = mvn.VNETDetector(S, {"train": T, "val": T}).to(dev)
+            with torch.no_grad():
+                for p, a in zip(det.parameters(), ws[r]):
+                    p.copy_(torch.tensor(a))
+            one = mvn.OnlineTrainer(det, L)
+            one.exp_avg.copy_(m0[r])
+            one.exp_avg_sq.copy_(v0[r])
+            one.step = int(step0[r])
+            if mode == "maml":
+                one.maml_training(rxw[r], txw[r], sup[r, :n].long(), qry[r, :n].long(), 0.1, True)
+            else:
+                one.online_training(txw[r, 2:3], rxw[r, 2:3], iterations=n, batch_idx=bidx[r, :n] if mode == "minibatch" else None,
+                                    full_word=mode == "full_word")
+            flat = torch.cat([p.detach().reshape(-1) for p in det.parameters()])
+            assert torch.equal(flat, bank.theta[r]) and torch.equal(flat, out2[r]), (mode, r)
+            assert torch.equal(one.exp_avg, bank.exp_avg[r]) and torch.equal(one.exp_avg_sq, bank.exp_avg_sq[r]), (mode, r)
+            assert torch.equal(bank.saved[r], torch.cat([torch.tensor(a).reshape(-1) for a in ws[r]]).to(dev))  # the input copy is not written
