@@ -7,6 +7,9 @@
 //                -L meta-viterbinet_amd -lmvn_hip -Wl,-rpath,'$ORIGIN/../meta-viterbinet_amd'
 //   file : int64 B,T,S | y[B*T] | priors[S] | W1[100] b1[100] W2[5000] b2[50] W3[S*50] b3[S] | tx[B*T]   (all fp32)
 //   out  : va_dec[B*T] | vnet_dec[B*T] | int64 va_counters[4] | int64 vnet_counters[4]
+//          and, at 16 states: int32 nerr[R] | enc[R*Tb] | theta[2*P]  -- one by-word block step for the first R = 4 words
+//          (mvn_vnet_byword_step_f32: Tb = 8 floor(T/8) symbols, RS with 2 parity bytes) and two trials of 5 full-word
+//          training iterations in one launch sequence (mvn_vnet_online_train_trials_f32, descriptors built here)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -77,5 +80,62 @@ int main(int argc, char **argv) {
     fclose(o);
     printf("VA  : bit errors %lld / %lld, frame errors %lld / %lld\n", (long long)c[0], (long long)c[1], (long long)c[2], (long long)c[3]);
     printf("VNET: bit errors %lld / %lld, frame errors %lld / %lld\n", (long long)c[4], (long long)c[5], (long long)c[6], (long long)c[7]);
+    if (S != 16 || B < 4 || T < 32) return 0;
+
+    // ---- one block step of the by-word evaluation for R words, then two independent trials of online training
+    const int R = 4, Tb = (T / 8) * 8, nsym = 2, K = Tb - 8 * nsym, P = 250 + 50 * 100 + 51 * S;
+    float *denc = nullptr, *dtheta = nullptr, *dm = nullptr, *dv = nullptr;
+    int32_t *dlab = nullptr, *dnerr = nullptr, *dstatus = nullptr;
+    HIP_OK(hipMalloc(&denc, (size_t)R * Tb * 4));
+    HIP_OK(hipMalloc(&dlab, (size_t)R * Tb * 4));
+    HIP_OK(hipMalloc(&dnerr, R * 4));
+    HIP_OK(hipMalloc(&dstatus, 2 * 4));
+    HIP_OK(hipMemsetAsync(dstatus, 0, 8, st));
+    // (the message of a word = the first K transmitted bits; the words' own row stride T is passed as the leading dimension)
+    MVN_OK_(mvn_vnet_byword_step_f32(dy, T, dtx, T, dW1, db1, dW2, db2, dW3, db3, nullptr, nullptr, Tb, nullptr, K, denc, Tb, nullptr,
+                                     Tb, dlab, Tb, dnerr, R, Tb, nsym, 0, S, st));
+    std::vector<float> theta0;  // flat parameters() order, one copy per trial
+    for (int t = 0; t < 2; ++t)
+        for (const std::vector<float> *a : {&W1, &b1, &W2, &b2, &W3, &b3}) theta0.insert(theta0.end(), a->begin(), a->end());
+    dtheta = to_device(theta0);
+    HIP_OK(hipMalloc(&dm, 2 * P * 4));
+    HIP_OK(hipMalloc(&dv, 2 * P * 4));
+    HIP_OK(hipMemsetAsync(dm, 0, 2 * P * 4, st));
+    HIP_OK(hipMemsetAsync(dv, 0, 2 * P * 4, st));
+    const int off[6] = {0, 100, 200, 5200, 5250, 5250 + 50 * S};
+    mvn_train_trial_t trials[2] = {};
+    for (int t = 0; t < 2; ++t) {
+        trials[t].y = dy + (size_t)t * T;             // word t, its first Tb symbols
+        trials[t].labels = dlab + (size_t)t * Tb;     // the trellis states the step kernel wrote for it
+        for (int a = 0; a < 6; ++a) trials[t].w_in[a] = trials[t].w_out[a] = dtheta + (size_t)t * P + off[a];
+        trials[t].adam_m = dm + (size_t)t * P;
+        trials[t].adam_v = dv + (size_t)t * P;
+        trials[t].status = dstatus + t;
+        trials[t].b1pow = trials[t].b2pow = 1.0;      // no Adam step taken yet
+        trials[t].n = 5;
+    }
+    mvn_train_trial_t *dtrials = nullptr;
+    HIP_OK(hipMalloc(&dtrials, sizeof trials));
+    HIP_OK(hipMemcpyAsync(dtrials, trials, sizeof trials, hipMemcpyHostToDevice, st));
+    const size_t tws_bytes = mvn_vnet_train_trials_workspace_bytes(S, Tb, 1, 2);
+    void *tws = nullptr;
+    HIP_OK(hipMalloc(&tws, tws_bytes ? tws_bytes : 16));
+    MVN_OK_(mvn_vnet_online_train_trials_f32(dtrials, 2, Tb, 0, 1e-3f, 0.9f, 0.999f, 1e-8f, S, tws, tws_bytes, st));
+    HIP_OK(hipStreamSynchronize(st));
+    std::vector<int32_t> nerr(R), status(2);
+    std::vector<float> enc((size_t)R * Tb), theta(2 * P);
+    HIP_OK(hipMemcpy(nerr.data(), dnerr, R * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(status.data(), dstatus, 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(enc.data(), denc, enc.size() * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(theta.data(), dtheta, theta.size() * 4, hipMemcpyDeviceToHost));
+    if (status[0] || status[1]) { fprintf(stderr, "mvn: %s\n", mvn_strerror(MVN_E_BARRIER)); return 4; }
+    o = fopen(argv[2], "ab");
+    if (!o) { perror("open out"); return 1; }
+    fwrite(nerr.data(), 4, nerr.size(), o);
+    fwrite(enc.data(), 4, enc.size(), o);
+    fwrite(theta.data(), 4, theta.size(), o);
+    fclose(o);
+    printf("by-word step: bit errors of the first %d words %d %d %d %d; 2 trials x 5 training iterations done\n", R, nerr[0], nerr[1],
+           nerr[2], nerr[3]);
     return 0;
 }

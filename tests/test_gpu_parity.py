@@ -876,9 +876,29 @@ def test_c_abi_demo(oracle, dev, tmp_path):
     rva = oracle.va_decode(y, pri, want_final=False)
     rvn = oracle.vnet_decode(y, w)
     assert np.array_equal(va, rva) and np.array_equal(vn, rvn)
+    counters = counters[:8]
     assert counters[:4].tolist() == oracle.count_errors(rva, tx).tolist()
     assert counters[4:].tolist() == oracle.count_errors(rvn, tx).tolist()
     assert "gfx950" in out.stdout
+    # the by-word step and the trial-batched training call of the demo (descriptors built in C++), against the Python side
+    R, Tb, nsym, P = 4, (T // 8) * 8, 2, 250 + 5000 + 51 * S
+    K = Tb - 8 * nsym
+    tail = raw[2 * B * T * 4 + 64:]
+    nerr = tail[:R * 4].view(np.int32)
+    enc = tail[R * 4: R * 4 + R * Tb * 4].view(np.float32).reshape(R, Tb)
+    theta = tail[R * 4 + R * Tb * 4:].view(np.float32).reshape(2, P)
+    yt, txt = torch.tensor(y, device=dev), torch.tensor(tx, device=dev)
+    det = _vnet_with(w, S, Tb, dev)
+    dec = det(yt[:R, :Tb].contiguous(), "val")
+    dmsg = mvn.rs_decode(dec, nsym)
+    assert nerr.tolist() == (dmsg != txt[:R, :K]).sum(dim=1).tolist()
+    renc = mvn.rs_encode(dmsg, nsym)
+    assert np.array_equal(enc, _np(renc))
+    for t in range(2):
+        d2 = _vnet_with(w, S, Tb, dev)
+        lw = dec[t:t + 1] if nerr[t] > 0 else renc[t:t + 1]
+        mvn.OnlineTrainer(d2, L).online_training(lw, yt[t:t + 1, :Tb].contiguous(), iterations=5, full_word=True)
+        assert np.array_equal(theta[t], _np(torch.cat([p_.detach().reshape(-1) for p_ in d2.parameters()]))), t
 
 
 def test_eval_by_word_online_meta_runs(golden, dev):
