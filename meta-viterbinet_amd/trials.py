@@ -14,7 +14,7 @@ MI355X's 256 CUs; here R trials step through their blocks together:
 All per-trial state lives in stacked device tensors (TrialBank); the reference's buffer of (received word, label word) pairs
 is a list of block numbers per trial (the words themselves stay where the step kernel wrote them).  Per trial, the results --
 ser_by_word, final weights, Adam moments -- are bit-identical to harness.eval_by_word run alone with the same draws
-(tests/test_gpu_parity.py::test_batched_trials_equal_sequential_runs).
+(tests/test_gpu_trials.py::test_batched_trials_equal_sequential_runs).
 """
 import ctypes
 from typing import List, Optional, Sequence
@@ -257,92 +257,91 @@ def _cohort_steps(bank, tx, rx, n_symbols, subframes_in_frame, draws, ser_by_wor
 
     buffers: List[List[int]] = [[] for _ in range(R)]  # trial r's buffer: the block numbers it holds, oldest first
     tables = None
-    done = torch.cuda.Event()
-    if True:  # (the driver holds the device guard)
-        for count in range(N):
-            pilot = 1 if count % subframes_in_frame == 0 else 0
-            rc = lib.mvn_vnet_byword_step_f32(ctypes.c_void_p(rx.data_ptr() + 4 * count * T), N * T,
-                                              ctypes.c_void_p(tx.data_ptr() + 4 * count * K), N * K, *wp, w_stride,
-                                              None, T, None, K, None, T, None, T,
-                                              ctypes.c_void_p(labels.data_ptr() + 4 * count * T), N * T,
-                                              ctypes.c_void_p(sync_dev.data_ptr()), R, T, n_symbols, pilot, S, stream)
-            _lib.check(rc, "mvn_vnet_byword_step_f32")
-            sync_host.copy_(sync_dev, non_blocking=True)
-            done.record(ts)
-            yield done  # the one host sync of the step (the reference has one per trial and block, trainer.py:305)
-            if status_np.any():
-                raise _lib.MvnError(f"trials {np.flatnonzero(status_np).tolist()}: {lib.mvn_strerror(-7).decode()}")
-            ser = ser_from_errors(nerr_np, K)  # the reference's value bit for bit (metrics.py:13-16)
-            if not pilot:
-                ser_by_word[:, count] = ser
-            push = ser <= ser_thresh  # trainer.py:319-324 (buffer_empty=True: the buffer only grows)
-            for r in np.flatnonzero(push):
-                buffers[r].append(count)
-            if record is not None:
-                record["nerr"][:, count] = nerr_np
-            # ---- online meta-learning (trainer.py:331-343): restart from the saved weights, all steps in one launch
-            if online_meta and count % meta_subframes == 0 and count >= meta_subframes:
-                act = [r for r in range(R) if len(buffers[r]) > 2]
-                if act:
-                    words = idx.np.view(np.int32)
-                    pos = 0
-                    offs, ns = np.empty(len(act), np.int64), np.empty(len(act), np.int32)
-                    for k, r in enumerate(act):
-                        buf = np.asarray(buffers[r], dtype=np.int32)
-                        j_hat = draws[r].j_hat_update(len(buf) - 2, meta_train_iterations, meta_j_num)
-                        n = j_hat.shape[0]
-                        # support j_hat + [-W .. -1], query j_hat: positions in the buffer, negative = from its end
-                        words[pos:pos + n * W] = buf[(j_hat[:, None] + sup_off[None, :]) % len(buf)].reshape(-1)
-                        words[pos + n * W:pos + n * (W + 1)] = buf[j_hat]
-                        offs[k], ns[k] = pos, n
-                        pos += n * (W + 1)
-                        if record is not None:
-                            record["meta"][r, count] = True
-                    a = np.asarray(act)
-                    d = d_meta[:len(act)]
-                    d["y"], d["labels"] = rx_p[a], lab_p[a]
-                    d["idx"] = np.uint64(idx.dev.data_ptr()) + (4 * offs).astype(np.uint64)
-                    d["query_idx"] = np.uint64(idx.dev.data_ptr()) + (4 * (offs + ns.astype(np.int64) * W)).astype(np.uint64)
-                    d["w_in"] = saved_p[a] if weights_init == "last_frame" else init_p[a]
-                    d["w_out"], d["w_out2"] = theta_p[a], saved_p[a]
-                    d["adam_m"], d["adam_v"], d["loss_out"], d["status"] = m_p[a], v_p[a], 0, status_p[a]
-                    d["b1pow"], d["b2pow"] = beta_powers(b1, bank.step[a]), beta_powers(b2, bank.step[a])
-                    d["n"], d["reserved"] = ns, 0
-                    bank.step[a] += ns
-                    idx.send(4 * pos)
-                    desc.send(len(act) * TRIAL_DTYPE.itemsize)
-                    rc = lib.mvn_vnet_maml_train_trials_f32(desc_meta_ptr, len(act), T, W, meta_lr, 1 if MAML else 0, bank.lr,
-                                                            b1, b2, bank.eps, S, _lib.ptr(ws), ws_bytes, stream)
-                    _lib.check(rc, "mvn_vnet_maml_train_trials_f32")
-            # ---- self-supervised training on the word just buffered (trainer.py:345-347)
-            if self_supervised and push.any():
-                act = np.flatnonzero(push)
-                if M and tables is None:
-                    for r in range(R):
-                        draws[r].batches(0, N, T, self_supervised_iterations, M)  # draws the trial's table
-                    tables = [draws[r]._table for r in range(R)]
-                    table_p = np.array([t.data_ptr() for t in tables], dtype=np.uint64)
-                d = d_onl[:len(act)]
-                d["y"] = rx_p[act] + np.uint64(4 * count * T)
-                d["labels"] = lab_p[act] + np.uint64(4 * count * T)
-                d["idx"] = table_p[act] + np.uint64(4 * count * self_supervised_iterations * M) if M else 0
-                d["query_idx"] = 0
-                d["w_in"] = saved_p[act] if meta_style_online_training else theta_p[act]  # metavnet_trainer.py:59
-                d["w_out"], d["w_out2"] = theta_p[act], 0
-                d["adam_m"], d["adam_v"], d["loss_out"], d["status"] = m_p[act], v_p[act], 0, status_p[act]
-                d["b1pow"], d["b2pow"] = beta_powers(b1, bank.step[act]), beta_powers(b2, bank.step[act])
-                d["n"], d["reserved"] = self_supervised_iterations, 0
-                bank.step[act] += self_supervised_iterations
-                if record is not None:
-                    record["trained"][act, count] = True
-                off = R * TRIAL_DTYPE.itemsize
-                desc.dev[off:off + len(act) * TRIAL_DTYPE.itemsize].copy_(desc.host[off:off + len(act) * TRIAL_DTYPE.itemsize],
-                                                                          non_blocking=True)
-                rc = lib.mvn_vnet_online_train_trials_f32(desc_onl_ptr, len(act), T, M, bank.lr, b1, b2, bank.eps, S,
-                                                          _lib.ptr(ws), ws_bytes, stream)
-                _lib.check(rc, "mvn_vnet_online_train_trials_f32")
+    done = torch.cuda.Event()  # (the driver holds the device guard)
+    for count in range(N):
+        pilot = 1 if count % subframes_in_frame == 0 else 0
+        rc = lib.mvn_vnet_byword_step_f32(ctypes.c_void_p(rx.data_ptr() + 4 * count * T), N * T,
+                                          ctypes.c_void_p(tx.data_ptr() + 4 * count * K), N * K, *wp, w_stride,
+                                          None, T, None, K, None, T, None, T,
+                                          ctypes.c_void_p(labels.data_ptr() + 4 * count * T), N * T,
+                                          ctypes.c_void_p(sync_dev.data_ptr()), R, T, n_symbols, pilot, S, stream)
+        _lib.check(rc, "mvn_vnet_byword_step_f32")
         sync_host.copy_(sync_dev, non_blocking=True)
         done.record(ts)
-        yield done
+        yield done  # the one host sync of the step (the reference has one per trial and block, trainer.py:305)
         if status_np.any():
             raise _lib.MvnError(f"trials {np.flatnonzero(status_np).tolist()}: {lib.mvn_strerror(-7).decode()}")
+        ser = ser_from_errors(nerr_np, K)  # the reference's value bit for bit (metrics.py:13-16)
+        if not pilot:
+            ser_by_word[:, count] = ser
+        push = ser <= ser_thresh  # trainer.py:319-324 (buffer_empty=True: the buffer only grows)
+        for r in np.flatnonzero(push):
+            buffers[r].append(count)
+        if record is not None:
+            record["nerr"][:, count] = nerr_np
+        # ---- online meta-learning (trainer.py:331-343): restart from the saved weights, all steps in one launch
+        if online_meta and count % meta_subframes == 0 and count >= meta_subframes:
+            act = [r for r in range(R) if len(buffers[r]) > 2]
+            if act:
+                words = idx.np.view(np.int32)
+                pos = 0
+                offs, ns = np.empty(len(act), np.int64), np.empty(len(act), np.int32)
+                for k, r in enumerate(act):
+                    buf = np.asarray(buffers[r], dtype=np.int32)
+                    j_hat = draws[r].j_hat_update(len(buf) - 2, meta_train_iterations, meta_j_num)
+                    n = j_hat.shape[0]
+                    # support j_hat + [-W .. -1], query j_hat: positions in the buffer, negative = from its end
+                    words[pos:pos + n * W] = buf[(j_hat[:, None] + sup_off[None, :]) % len(buf)].reshape(-1)
+                    words[pos + n * W:pos + n * (W + 1)] = buf[j_hat]
+                    offs[k], ns[k] = pos, n
+                    pos += n * (W + 1)
+                    if record is not None:
+                        record["meta"][r, count] = True
+                a = np.asarray(act)
+                d = d_meta[:len(act)]
+                d["y"], d["labels"] = rx_p[a], lab_p[a]
+                d["idx"] = np.uint64(idx.dev.data_ptr()) + (4 * offs).astype(np.uint64)
+                d["query_idx"] = np.uint64(idx.dev.data_ptr()) + (4 * (offs + ns.astype(np.int64) * W)).astype(np.uint64)
+                d["w_in"] = saved_p[a] if weights_init == "last_frame" else init_p[a]
+                d["w_out"], d["w_out2"] = theta_p[a], saved_p[a]
+                d["adam_m"], d["adam_v"], d["loss_out"], d["status"] = m_p[a], v_p[a], 0, status_p[a]
+                d["b1pow"], d["b2pow"] = beta_powers(b1, bank.step[a]), beta_powers(b2, bank.step[a])
+                d["n"], d["reserved"] = ns, 0
+                bank.step[a] += ns
+                idx.send(4 * pos)
+                desc.send(len(act) * TRIAL_DTYPE.itemsize)
+                rc = lib.mvn_vnet_maml_train_trials_f32(desc_meta_ptr, len(act), T, W, meta_lr, 1 if MAML else 0, bank.lr,
+                                                        b1, b2, bank.eps, S, _lib.ptr(ws), ws_bytes, stream)
+                _lib.check(rc, "mvn_vnet_maml_train_trials_f32")
+        # ---- self-supervised training on the word just buffered (trainer.py:345-347)
+        if self_supervised and push.any():
+            act = np.flatnonzero(push)
+            if M and tables is None:
+                for r in range(R):
+                    draws[r].batches(0, N, T, self_supervised_iterations, M)  # draws the trial's table
+                tables = [draws[r]._table for r in range(R)]
+                table_p = np.array([t.data_ptr() for t in tables], dtype=np.uint64)
+            d = d_onl[:len(act)]
+            d["y"] = rx_p[act] + np.uint64(4 * count * T)
+            d["labels"] = lab_p[act] + np.uint64(4 * count * T)
+            d["idx"] = table_p[act] + np.uint64(4 * count * self_supervised_iterations * M) if M else 0
+            d["query_idx"] = 0
+            d["w_in"] = saved_p[act] if meta_style_online_training else theta_p[act]  # metavnet_trainer.py:59
+            d["w_out"], d["w_out2"] = theta_p[act], 0
+            d["adam_m"], d["adam_v"], d["loss_out"], d["status"] = m_p[act], v_p[act], 0, status_p[act]
+            d["b1pow"], d["b2pow"] = beta_powers(b1, bank.step[act]), beta_powers(b2, bank.step[act])
+            d["n"], d["reserved"] = self_supervised_iterations, 0
+            bank.step[act] += self_supervised_iterations
+            if record is not None:
+                record["trained"][act, count] = True
+            off = R * TRIAL_DTYPE.itemsize
+            desc.dev[off:off + len(act) * TRIAL_DTYPE.itemsize].copy_(desc.host[off:off + len(act) * TRIAL_DTYPE.itemsize],
+                                                                      non_blocking=True)
+            rc = lib.mvn_vnet_online_train_trials_f32(desc_onl_ptr, len(act), T, M, bank.lr, b1, b2, bank.eps, S,
+                                                      _lib.ptr(ws), ws_bytes, stream)
+            _lib.check(rc, "mvn_vnet_online_train_trials_f32")
+    sync_host.copy_(sync_dev, non_blocking=True)
+    done.record(ts)
+    yield done
+    if status_np.any():
+        raise _lib.MvnError(f"trials {np.flatnonzero(status_np).tolist()}: {lib.mvn_strerror(-7).decode()}")
