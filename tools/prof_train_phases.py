@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 import meta_viterbinet_amd as mvn  # noqa: E402
 
 dev = torch.device("cuda:0")
-T, L, S, N = 136, 4, 16, 200
+T, L, S, N = 136, 4, 16, 420
 names = ["h1 = sigmoid(W1 y + b1)", "z2 = h1 W2^T (MFMA)", "logits = relu(z2) W3^T (MFMA)", "softmax / CE / dlogits",
          "dz2, dW3, db3", "dz1 (MFMA), dW2 (MFMA), db2", "dW1, db1"]
 for full in (False, True):
@@ -37,7 +37,7 @@ for full in (False, True):
     for _ in range(3):
         loss = tr.online_training(tx, rx, iterations=N, full_word=full, return_loss=True)
     torch.cuda.synchronize()
-    st = loss[102:150].cpu().numpy().view(np.uint64).astype(np.int64)
+    st = loss[102:102 + 304].cpu().numpy().view(np.uint64).astype(np.int64)
     # stamps 0..7: the LAST chunk of iteration 100 (grad_chunk start, then after each barrier); 8: iteration start; 9: after Adam
     it_total = st[9] - st[8]
     print(f"--- {'full word (136 samples = 5 chunks)' if full else 'minibatch (32 samples = 1 chunk)'}: iteration 100 = {it_total} cycles of s_memtime (100 MHz counter x24 = 2.4 GHz?)")
@@ -45,6 +45,10 @@ for full in (False, True):
         print(f"  {names[k]:36s} {st[k+1]-st[k]:7d}")
     print(f"    wave 0 inside the hidden-layer phase: dz1 tile {st[11]-st[10]}, dW2 tile {st[12]-st[11]}, dW2 tile {st[13]-st[12]}, "
           f"db2 {st[14]-st[13]}, wait at the barrier {st[6]-st[14]}")
+    print("    cycles from a phase's start to each wave's arrival at the barrier that ends it (waves 0..15):")
+    for ph in range(8):
+        start = st[ph] if ph < 7 else st[7]
+        print(f"      {(names + ['Adam'])[ph][:28]:28s}", " ".join(f"{int(st[24 + 16 * ph + w] - start):5d}" for w in range(16)))
     print(f"    wave 0 inside the z2 phase: barrier -> tile start {st[16]-st[1]}, operand reads + 25 MFMAs issued {st[17]-st[16]}, "
           f"bias + store {st[18]-st[17]}, wait at the barrier {st[2]-st[18]}")
     print(f"  {'chunk total':36s} {st[7]-st[0]:7d}")
