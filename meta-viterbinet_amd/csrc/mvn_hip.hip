@@ -806,9 +806,9 @@ int trials_per_launch(int R, int fit) {
 }
 
 // Many trials: one workgroup per CHUNK and trial finishes a trial soonest, one workgroup per TRIAL gets the most trials through
-// a CU per second (no exchange, no workgroup waiting for a pass it has no chunk of): a full-word iteration costs 10.6 us on 5
-// CUs or 34.7 us on one, a second-order meta-learning step 38 us on 9 or 154 us on one (first order 24 / 72;
-// profiles/r0{2,3}_time_online_training.txt).  With R trials the chunked form needs ceil(R / (CUs / groups)) launches one after
+// a CU per second (no exchange, no workgroup waiting for a pass it has no chunk of): a full-word iteration costs 9.9 us on 5
+// CUs or 31.0 us on one, a second-order meta-learning step 39 us on 5 or 133 us on one (first order 21 / 66;
+// profiles/r03_time_online_training.txt).  With R trials the chunked form needs ceil(R / (CUs / groups)) launches one after
 // the other, the one-workgroup form ceil(R / CUs) rounds of `slowdown` times the length: take whichever ends first.  (Both
 // forms give the same bits.)
 bool one_workgroup_per_trial_is_faster(int R, int groups, int cus, double slowdown) {
@@ -840,7 +840,7 @@ int launch_online_train(const mvn_train_trial_t &one, const mvn_train_trial_t *m
     const size_t stride = groups >= 2 ? trial_workspace_floats(S, groups) : 0;
     if (groups < 2 || !workspace || sw(SW_TRAIN_GROUPS) == '0' || groups > cus ||
         workspace_bytes < (many ? (size_t)R * stride * sizeof(float) : train_groups_workspace_bytes(S, groups)) ||
-        (many && sw(SW_TRAIN_GROUPS) != '1' && one_workgroup_per_trial_is_faster(R, groups, cus, 3.3)))
+        (many && sw(SW_TRAIN_GROUPS) != '1' && one_workgroup_per_trial_is_faster(R, groups, cus, 3.1)))
         groups = 0;
     if (groups && (reinterpret_cast<uintptr_t>(workspace) & 15)) return MVN_E_WORKSPACE;
     if (!groups) {  // one workgroup per trial
@@ -895,7 +895,7 @@ int launch_maml_train(const mvn_train_trial_t &one, const mvn_train_trial_t *man
     const size_t stride = groups >= 2 ? trial_workspace_floats(S, groups) : 0;
     if (groups < 2 || !workspace || sw(SW_TRAIN_GROUPS) == '0' || groups > cus ||
         workspace_bytes < (many ? (size_t)R * stride * sizeof(float) : maml_groups_workspace_bytes(S, groups)) ||
-        (many && sw(SW_TRAIN_GROUPS) != '1' && one_workgroup_per_trial_is_faster(R, groups, cus, second_order ? 4.0 : 3.0)))
+        (many && sw(SW_TRAIN_GROUPS) != '1' && one_workgroup_per_trial_is_faster(R, groups, cus, second_order ? 3.4 : 3.1)))
         groups = 0;
     if (groups && (reinterpret_cast<uintptr_t>(workspace) & 15)) return MVN_E_WORKSPACE;
     if (!groups) {
