@@ -287,7 +287,7 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
         # the library's own choice (mvn_hip.hip: one_workgroup_per_trial_is_faster): chunked passes finish a trial soonest, one
         # workgroup per trial gets the most trials through a CU per second
         fit = max(1, n_cu.value // groups)
-        if groups > 1 and (4.0 if maml else 3.3) * -(-trials // n_cu.value) < -(-trials // fit):
+        if groups > 1 and (3.4 if maml else 3.1) * -(-trials // n_cu.value) < -(-trials // fit):
             groups, fit = 1, n_cu.value
         per_launch = min(trials, fit)
         return {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
@@ -350,9 +350,9 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
                 "what": f"{R4} independent trial(s) per GPU stepping together (replicas: block k's weights depend on the blocks before it); "
                         "per block step one byword_step_kernel launch, one host sync, and for the trials that train one launch sequence of "
                         "the meta-learning and the online-training kernel (gridDim.y = trial): one workgroup per 32-sample chunk and trial "
-                        "(9 / 5 workgroups, never more per launch than CUs) for few trials, one workgroup per trial from ~130-200 trials on "
+                        "(5 workgroups, never more per launch than CUs) for few trials, one workgroup per trial from ~160 trials on "
                         "(more trials through a CU per second; same bits); one all_gather of ser_by_word[300] per trial",
-                "roofline": training_roofline(st4, R4, 200, T2, True, 9),
+                "roofline": training_roofline(st4, R4, 200, T2, True, 5),
                 "note": "training passes run one workgroup per 32-sample chunk and trial, gradients exchanged through a per-trial workspace "
                         "with one device-wide barrier per pass (DESIGN.md 5.6, 5.7)"})
     return out

@@ -2,6 +2,11 @@ set -e
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03p
 mkdir -p $O
+# the counter passes first: bench.py reads profiles/traffic.json and valu_insts.json and ignores them unless they carry the sha of
+# the kernel sources it runs (they are copied into profiles/ here, on the box; copy them again from gpurun_out/ at home)
+cd $R && bash tools/pmc_traffic.sh gpurun_out/r03p/pmc > $O/pmc.log 2>&1
+cp $O/pmc/traffic.json $O/pmc/valu_insts.json $R/profiles/
+echo pmc done
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 echo bench done
@@ -13,8 +18,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kh -o t -- python3 $R
 cp $O/kh/t_kernel_stats.csv $O/headline_kernel_stats.csv
 python3 $R/tools/stats_by_grid.py $O/kh/t_kernel_trace.csv > $O/headline_by_grid.csv
 echo kh done
-cd $R && bash tools/pmc_traffic.sh gpurun_out/r03p/pmc > $O/pmc.log 2>&1
-echo pmc done
+cd $R
 python3 tools/time_trials.py 1 16 28 51 102 128 204 256 512 2>&1 | grep -v amdgpu.ids > $O/time_trials.txt
 python3 tools/time_step.py 2>&1 | grep -v amdgpu.ids > $O/time_step.txt
 python3 tools/time_online.py 2>&1 | grep -v amdgpu.ids > $O/time_online_training.txt

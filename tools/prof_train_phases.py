@@ -27,7 +27,11 @@ import meta_viterbinet_amd as mvn  # noqa: E402
 dev = torch.device("cuda:0")
 T, L, S, N = 136, 4, 16, 420
 names = ["h1 = sigmoid(W1 y + b1)", "z2 = h1 W2^T (MFMA)", "logits = relu(z2) W3^T (MFMA)", "softmax / CE / dlogits",
-         "dz2, dW3, db3", "dz1 (MFMA), dW2 (MFMA), db2", "dW1, db1"]
+         "dz2, dW3, db3", "dz1 (MFMA), dW2 units 0..47 (MFMA)", "dW1, db1, db2, dW2 units 48, 49"]
+os.environ["MVN_TRAIN_GROUPS"] = "0"  # the full-word run on the one-workgroup kernel too: the stamps live there
+mvn._lib.reload_switches()
+print("(the stamps cost: an iteration of this build is ~25 % longer than the production build's; read the table for proportions and "
+      "for WHICH wave a phase waits for)")
 for full in (False, True):
     torch.manual_seed(0)
     tx = torch.randint(0, 2, (1, T)).float().to(dev)
@@ -40,11 +44,11 @@ for full in (False, True):
     st = loss[102:102 + 304].cpu().numpy().view(np.uint64).astype(np.int64)
     # stamps 0..7: the LAST chunk of iteration 100 (grad_chunk start, then after each barrier); 8: iteration start; 9: after Adam
     it_total = st[9] - st[8]
-    print(f"--- {'full word (136 samples = 5 chunks)' if full else 'minibatch (32 samples = 1 chunk)'}: iteration 100 = {it_total} cycles of s_memtime (100 MHz counter x24 = 2.4 GHz?)")
+    print(f"--- {'full word (136 samples = 5 chunks)' if full else 'minibatch (32 samples = 1 chunk)'}: iteration 100 = {it_total} cycles of s_memtime (2.4 GHz)")
     for k in range(7):
         print(f"  {names[k]:36s} {st[k+1]-st[k]:7d}")
-    print(f"    wave 0 inside the hidden-layer phase: dz1 tile {st[11]-st[10]}, dW2 tile {st[12]-st[11]}, dW2 tile {st[13]-st[12]}, "
-          f"db2 {st[14]-st[13]}, wait at the barrier {st[6]-st[14]}")
+    print(f"    wave 0 inside the hidden-layer phase: operands + 32 MFMAs issued {st[11]-st[10]}, results + epilogue {st[12]-st[11]}, "
+          f"wait at the barrier {st[6]-st[12]}")
     print("    cycles from a phase's start to each wave's arrival at the barrier that ends it (waves 0..15):")
     for ph in range(8):
         start = st[ph] if ph < 7 else st[7]
