@@ -641,15 +641,18 @@ def test_online_training_golden(golden, dev):
     assert det(torch.tensor(g["rx"], device=dev), "val").shape == (1, T)
 
 
-@pytest.mark.parametrize("n_iter,full_word", [(1, False), (6, False), (40, False), (3, True)])
-def test_online_training_vs_torch(dev, n_iter, full_word):
+@pytest.mark.parametrize("n_iter,full_word,M", [(1, False, 32), (6, False, 32), (40, False, 32), (3, True, 32),
+                                               (6, False, 8), (6, False, 17), (5, False, 64), (4, False, 100)])
+def test_online_training_vs_torch(dev, n_iter, full_word, M):
+    """M: minibatch size -- 32 is select_batch's; smaller ones leave padding rows in the one chunk, larger ones take several chunks
+    per iteration (the first of which writes the gradient vector, the others add to it)."""
     S, T, L = 16, 136, 4
-    rng = np.random.RandomState(n_iter)
+    rng = np.random.RandomState(n_iter + M)
     w = _rand_weights(S, rng)
     tx = rng.randint(0, 2, (1, T)).astype(np.float32)
     y = rng.normal(0, 1.5, (1, T)).astype(np.float32)
     labels = mvn.calculate_states(L, torch.tensor(tx)).numpy()
-    idx = np.stack([rng.choice(np.arange(1, T), 32, replace=False) for _ in range(n_iter)]).astype(np.int32)
+    idx = np.stack([rng.choice(np.arange(1, T), M, replace=False) for _ in range(n_iter)]).astype(np.int32)
     ref_w, ref_loss = _torch_online_ref(w, y[0], labels, idx, 1e-3, n_iter, full_word)
     det = _vnet_with(w, S, T, dev)
     tr = mvn.OnlineTrainer(det, L)
