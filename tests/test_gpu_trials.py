@@ -240,7 +240,7 @@ def test_abandoned_group_barrier_is_reported_not_silent(golden, dev):
 
 def test_two_training_launches_in_flight(golden, dev):
     """Two one-workgroup-per-chunk training calls in flight at once on two streams (each with its own workspace and barrier
-    counter; 5 + 9 workgroups on a 256-CU device): results identical to running them one after the other."""
+    counter; 5 + 5 workgroups on a 256-CU device): results identical to running them one after the other."""
     g7 = golden("g7_by_word")
     w = [g7[f"w{i}"] for i in range(6)]
     T = 136
