@@ -54,7 +54,7 @@ typedef void *mvn_stream_t; /* hipStream_t */
 
 #define MVN_E_BARRIER (-7)   /* (status words only) a training launch abandoned its device-wide barrier */
 
-#define MVN_ABI_VERSION 4 /* 4: + trial-batched training / by-word step, status words; 3: training with a workspace; 2: kernel-name queries */
+#define MVN_ABI_VERSION 5 /* 5: + mvn_vnet_train_kernel_name; 4: + trial-batched training / by-word step, status words; 3: training with a workspace; 2: kernel-name queries */
 
 /* ABI version of the loaded library (== MVN_ABI_VERSION). */
 int mvn_version(void);
@@ -264,6 +264,20 @@ int mvn_vnet_online_train_trials_f32(const mvn_train_trial_t *trials, int32_t R,
 int mvn_vnet_maml_train_trials_f32(const mvn_train_trial_t *trials, int32_t R, int32_t T, int32_t W, float meta_lr,
                                    int32_t second_order, float lr, float beta1, float beta2, float eps, int32_t S,
                                    void *workspace, size_t workspace_bytes, mvn_stream_t stream);
+
+/*
+ * Introspection for tests and profiling tools (no reference counterpart): which device kernel, in which form, a training
+ * call launches for these shapes on the current device -- the launchers' own decision (MVN_TRAIN_GROUPS switch, CU count,
+ * the "one workgroup per chunk and trial" / "one workgroup per trial" rule for many trials).
+ *   kind: 0 = mvn_vnet_online_train_*, 1 = mvn_vnet_maml_train_* first order, 2 = second order;
+ *   R: 0 = the single-trial entry points, > 0 = the *_trials_* entry points with R trials that run (n > 0);
+ *   M_or_W: minibatch size M (0 = whole word) for kind 0, support words W for kinds 1, 2;
+ *   workspace_bytes: what the call passes (0 = no workspace).
+ * name (HOST pointer) receives e.g. "maml_train_kernel<16, true> 1x176" or "online_train_groups_kernel<16, true> 5x51 in 4
+ * launches" (workgroups per trial x trials per launch).  Returns 0, MVN_E_DIMS, MVN_E_STATES or MVN_E_NULL.
+ */
+int mvn_vnet_train_kernel_name(int32_t kind, int32_t R, int32_t T, int32_t M_or_W, int32_t S, size_t workspace_bytes, char *name,
+                               int32_t name_len);
 
 /*
  * One block step of Trainer.eval_by_word (python_code/trainers/trainer.py:292-316 and the buffer entry of :322-324) for R

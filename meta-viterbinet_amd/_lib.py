@@ -9,7 +9,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVN_LIB_PATH", os.path.join(_PKG, "libmvn_hip.so"))  # override: A/B builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -47,6 +47,7 @@ SIGNATURES = {
     "mvn_vnet_online_train_trials_f32": (ctypes.c_int, [_vp, _i32, _i32, _i32] + [ctypes.c_float] * 4 + [_i32, _vp, ctypes.c_size_t, _vp]),
     "mvn_vnet_maml_train_trials_f32": (ctypes.c_int, [_vp, _i32, _i32, _i32, ctypes.c_float, _i32] + [ctypes.c_float] * 4 +
                                        [_i32, _vp, ctypes.c_size_t, _vp]),
+    "mvn_vnet_train_kernel_name": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, ctypes.c_size_t, ctypes.c_char_p, _i32]),
     "mvn_vnet_byword_step_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64] + [_vp] * 6 + [ctypes.POINTER(ctypes.c_int64)] +
                                  [_vp, _i64] * 4 + [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "mvn_reload_switches": (None, []),
@@ -65,22 +66,27 @@ class MvnError(RuntimeError):
     """A libmvn_hip.so call returned non-zero."""
 
 
+def load_variant(path: str):
+    """Another build of the library (an A/B build, the tests' -DMVN_TEST_HOOKS build) with the same bindings; not cached."""
+    if not os.path.exists(path):
+        raise MvnError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the 'val' path.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mvn_version() != ABI_VERSION:
+        raise MvnError(f"{os.path.basename(path)} ABI {lib.mvn_version()} != expected {ABI_VERSION}")
+    return lib
+
+
 def load():
     """Load the HIP library; raises (never falls back) if it is absent."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise MvnError(
-                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the 'val' path.")
-        lib = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
-            fn.restype = res
-            fn.argtypes = args
-        if lib.mvn_version() != ABI_VERSION:
-            raise MvnError(f"libmvn_hip.so ABI {lib.mvn_version()} != expected {ABI_VERSION}")
-        _lib = lib
+        _lib = load_variant(LIB_PATH)
     return _lib
 
 

@@ -24,6 +24,8 @@
 #include <math.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <type_traits>
 
 #include "../../include/mvn.h"
@@ -550,18 +552,22 @@ enum Switch { SW_UNFUSED, SW_COOP, SW_FUSEDN, SW_GENERIC_SWEEP, SW_VA256, SW_VA_
               SW_TRAIN_GROUPS, SW_COUNT };
 const char *const kSwitchNames[SW_COUNT] = {"MVN_UNFUSED", "MVN_COOP", "MVN_FUSEDN", "MVN_GENERIC_SWEEP", "MVN_VA256",
                                             "MVN_VA_INPLACE", "MVN_VA16", "MVN_SWEEP_INPLACE", "MVN_SWEEP16", "MVN_TRAIN_GROUPS"};
-char g_switch[SW_COUNT];
-bool g_switches_loaded = false;
+// The library may be called from several host threads: the table is atomics (a reload while another thread launches gives that
+// launch either the old or the new value of a switch, never a torn one), filled under a mutex.
+std::atomic<char> g_switch[SW_COUNT];
+std::atomic<bool> g_switches_loaded{false};
+std::mutex g_switch_mutex;
 void load_switches() {
+    std::lock_guard<std::mutex> lock(g_switch_mutex);
     for (int i = 0; i < SW_COUNT; ++i) {
         const char *e = getenv(kSwitchNames[i]);
-        g_switch[i] = e ? e[0] : 0;
+        g_switch[i].store(e ? e[0] : 0, std::memory_order_relaxed);
     }
-    g_switches_loaded = true;
+    g_switches_loaded.store(true, std::memory_order_release);
 }
 inline char sw(Switch i) {
-    if (!g_switches_loaded) load_switches();
-    return g_switch[i];
+    if (!g_switches_loaded.load(std::memory_order_acquire)) load_switches();
+    return g_switch[i].load(std::memory_order_relaxed);
 }
 
 // MVN_UNFUSED=1 forces the two-kernel ViterbiNet path (MLP -> logits -> sweep) for testing.
@@ -582,7 +588,8 @@ int fusedn_tiles() {
     return kFusedNDefault;
 }
 
-// The opt-in to more than 64 KB of dynamic LDS is per function (and device): raised once, remembered
+// The opt-in to more than 64 KB of dynamic LDS is per function (and device): raised once, remembered (under a mutex: the
+// by-word evaluation of several host threads comes through here once per launch; uncontended it costs ~20 ns)
 int ensure_dynamic_lds(const void *fn, size_t bytes) {
     struct Entry {
         const void *fn;
@@ -591,8 +598,10 @@ int ensure_dynamic_lds(const void *fn, size_t bytes) {
     };
     static Entry seen[64];
     static int n_seen = 0;
+    static std::mutex seen_mutex;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lock(seen_mutex);
     for (int i = 0; i < n_seen; ++i)
         if (seen[i].fn == fn && seen[i].dev == dev) {
             if (seen[i].bytes >= bytes) return 0;
@@ -768,15 +777,15 @@ bool valid_states(int S) { return S >= 2 && S <= 256 && (S & (S - 1)) == 0; }
 // CUs of the current device (cached per device): the one-workgroup-per-chunk training kernels need one CU per workgroup to be
 // resident at once (each workgroup takes most of a CU's LDS)
 int current_device_cus() {
-    static int cached[64] = {0};
+    static std::atomic<int> cached[64];  // (zero-initialised; two threads that both miss store the same value)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    if (!cached[dev]) {
-        int n = 0;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (!n) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        cached[dev] = n;
+        cached[dev].store(n, std::memory_order_relaxed);
     }
-    return cached[dev];
+    return n;
 }
 
 
@@ -831,17 +840,35 @@ int dispatch_states(int S, bool many, Launch launch) {
     return launch(std::integral_constant<int, 0>{});
 }
 
+// Workgroups per trial a training call runs with (0 = one workgroup per trial): ONE decision function for the launchers and
+// for mvn_vnet_train_kernel_name, so that the form a test or a profile is told is the form that runs.  `many`: the
+// trial-batched entry points (R trials); has_workspace / workspace_bytes as the caller passed them.
+int plan_online_groups(bool many, int R, int T, int M, int S, bool has_workspace, size_t workspace_bytes) {
+    const int groups = M > 0 ? 0 : online_groups(T);  // minibatch iterations are one chunk: nothing to spread
+    const int cus = current_device_cus();
+    if (groups < 2 || !has_workspace || sw(SW_TRAIN_GROUPS) == '0' || groups > cus) return 0;
+    if (workspace_bytes < (many ? (size_t)R * trial_workspace_floats(S, groups) * sizeof(float) : train_groups_workspace_bytes(S, groups)))
+        return 0;
+    if (many && sw(SW_TRAIN_GROUPS) != '1' && one_workgroup_per_trial_is_faster(R, groups, cus, 3.1)) return 0;
+    return groups;
+}
+int plan_maml_groups(bool many, int R, int T, int W, int second_order, int S, bool has_workspace, size_t workspace_bytes) {
+    const int groups = maml_groups(T, W, second_order);  // one workgroup per chunk of the largest pass
+    const int cus = current_device_cus();
+    if (groups < 2 || !has_workspace || sw(SW_TRAIN_GROUPS) == '0' || groups > cus) return 0;
+    if (workspace_bytes < (many ? (size_t)R * trial_workspace_floats(S, groups) * sizeof(float) : maml_groups_workspace_bytes(S, groups)))
+        return 0;
+    if (many && sw(SW_TRAIN_GROUPS) != '1' && one_workgroup_per_trial_is_faster(R, groups, cus, second_order ? 3.4 : 3.1)) return 0;
+    return groups;
+}
+
 int launch_online_train(const mvn_train_trial_t &one, const mvn_train_trial_t *many, int R, int T, int M, float lr, float beta1,
                         float beta2, float eps, int S, void *workspace, size_t workspace_bytes, hipStream_t st) {
     const size_t lds = online_train_lds_bytes(S);
     const int lds_floats = (int)online_train_lds_floats(S);
-    int groups = M > 0 ? 0 : online_groups(T);  // minibatch iterations are one chunk: nothing to spread
+    const int groups = plan_online_groups(many != nullptr, R, T, M, S, workspace != nullptr, workspace_bytes);
     const int cus = current_device_cus();
     const size_t stride = groups >= 2 ? trial_workspace_floats(S, groups) : 0;
-    if (groups < 2 || !workspace || sw(SW_TRAIN_GROUPS) == '0' || groups > cus ||
-        workspace_bytes < (many ? (size_t)R * stride * sizeof(float) : train_groups_workspace_bytes(S, groups)) ||
-        (many && sw(SW_TRAIN_GROUPS) != '1' && one_workgroup_per_trial_is_faster(R, groups, cus, 3.1)))
-        groups = 0;
     if (groups && (reinterpret_cast<uintptr_t>(workspace) & 15)) return MVN_E_WORKSPACE;
     if (!groups) {  // one workgroup per trial
         return dispatch_states(S, many != nullptr, [&](auto sc) -> int {
@@ -866,7 +893,7 @@ int launch_online_train(const mvn_train_trial_t &one, const mvn_train_trial_t *m
         float *wsr = (float *)workspace + (size_t)r0 * stride;
         hipError_t e = clear_group_syncs(wsr, stride, nr, st);
         if (e != hipSuccess) return (int)e;
-        const GroupLaunch gl = {wsr, (long long)stride, (unsigned)((many ? stride : ws_floats_one) * sizeof(float)), g_group_spin_limit, g_group_phantoms};
+        const GroupLaunch gl = {wsr, (long long)stride, (unsigned)((many ? stride : ws_floats_one) * sizeof(float)), group_spin_limit(), group_phantoms()};
         const int rc = dispatch_states(S, many != nullptr, [&](auto sc) -> int {
             constexpr int SC = decltype(sc)::value;
             if (many) {
@@ -890,13 +917,9 @@ int launch_maml_train(const mvn_train_trial_t &one, const mvn_train_trial_t *man
                       size_t workspace_bytes, hipStream_t st) {
     const size_t lds = maml_train_lds_floats(S) * sizeof(float);
     const int lds_floats = (int)maml_train_lds_floats(S);
-    int groups = maml_groups(T, W, second_order);  // one workgroup per chunk of the largest pass
+    const int groups = plan_maml_groups(many != nullptr, R, T, W, second_order, S, workspace != nullptr, workspace_bytes);
     const int cus = current_device_cus();
     const size_t stride = groups >= 2 ? trial_workspace_floats(S, groups) : 0;
-    if (groups < 2 || !workspace || sw(SW_TRAIN_GROUPS) == '0' || groups > cus ||
-        workspace_bytes < (many ? (size_t)R * stride * sizeof(float) : maml_groups_workspace_bytes(S, groups)) ||
-        (many && sw(SW_TRAIN_GROUPS) != '1' && one_workgroup_per_trial_is_faster(R, groups, cus, second_order ? 3.4 : 3.1)))
-        groups = 0;
     if (groups && (reinterpret_cast<uintptr_t>(workspace) & 15)) return MVN_E_WORKSPACE;
     if (!groups) {
         return dispatch_states(S, many != nullptr, [&](auto sc) -> int {
@@ -920,7 +943,7 @@ int launch_maml_train(const mvn_train_trial_t &one, const mvn_train_trial_t *man
         float *wsr = (float *)workspace + (size_t)r0 * stride;
         hipError_t e = clear_group_syncs(wsr, stride, nr, st);
         if (e != hipSuccess) return (int)e;
-        const GroupLaunch gl = {wsr, (long long)stride, (unsigned)((many ? stride : ws_floats_one) * sizeof(float)), g_group_spin_limit, g_group_phantoms};
+        const GroupLaunch gl = {wsr, (long long)stride, (unsigned)((many ? stride : ws_floats_one) * sizeof(float)), group_spin_limit(), group_phantoms()};
         const int rc = dispatch_states(S, many != nullptr, [&](auto sc) -> int {
             constexpr int SC = decltype(sc)::value;
             if (many) {
@@ -1227,6 +1250,31 @@ int mvn_vnet_maml_train_trials_f32(const mvn_train_trial_t *trials, int32_t R, i
                              workspace_bytes, (hipStream_t)stream);
 }
 
+int mvn_vnet_train_kernel_name(int32_t kind, int32_t R, int32_t T, int32_t M_or_W, int32_t S, size_t workspace_bytes, char *name,
+                               int32_t name_len) {
+    if (kind < 0 || kind > 2 || R < 0 || T < 1 || M_or_W < 0 || (kind > 0 && M_or_W < 1)) return MVN_E_DIMS;
+    if (!valid_states(S) || S > 32) return MVN_E_STATES;
+    if (!name || name_len < 1) return MVN_E_NULL;
+    const bool many = R > 0;
+    const int n_trials = many ? R : 1;
+    const int groups = kind == 0 ? plan_online_groups(many, n_trials, T, M_or_W, S, workspace_bytes > 0, workspace_bytes)
+                                 : plan_maml_groups(many, n_trials, T, M_or_W, kind == 2, S, workspace_bytes > 0, workspace_bytes);
+    const int sc = S == 16 ? 16 : (S == 32 && !many) ? 32 : 0;  // dispatch_states
+    const char *base = kind == 0 ? "online_train" : "maml_train";
+    if (!groups) {
+        snprintf(name, (size_t)name_len, "%s_kernel<%d, %s> 1x%d", base, sc, many ? "true" : "false", n_trials);
+    } else {
+        const int per_launch = many ? trials_per_launch(n_trials, current_device_cus() / groups) : 1;
+        const int launches = (n_trials + per_launch - 1) / per_launch;
+        if (launches > 1)
+            snprintf(name, (size_t)name_len, "%s_groups_kernel<%d, %s> %dx%d in %d launches", base, sc, many ? "true" : "false", groups,
+                     per_launch, launches);
+        else
+            snprintf(name, (size_t)name_len, "%s_groups_kernel<%d, %s> %dx%d", base, sc, many ? "true" : "false", groups, per_launch);
+    }
+    return MVN_OK;
+}
+
 int mvn_vnet_byword_step_f32(const float *rx, int64_t rx_ld, const float *tx, int64_t tx_ld, const float *W1, const float *b1,
                              const float *W2, const float *b2, const float *W3, const float *b3, const int64_t *w_stride,
                              float *dec, int64_t dec_ld, float *msg, int64_t msg_ld, float *enc, int64_t enc_ld,
@@ -1260,12 +1308,16 @@ int mvn_vnet_byword_step_f32(const float *rx, int64_t rx_ld, const float *tx, in
 
 void mvn_reload_switches(void) { load_switches(); }
 
-/* test hooks (not part of include/mvn.h): spin limit of the training kernels' device-wide barrier, and phantom workgroups
- * every barrier additionally waits for (> 0 forces the give-up path); negative arguments leave a setting unchanged */
+#ifdef MVN_TEST_HOOKS
+/* Test hooks -- compiled into the tests' build of the library only (-DMVN_TEST_HOOKS: libmvn_hip_hooks.so, built by
+ * __graft_entry__.build_hip_hooks and loaded through MVN_LIB_PATH / _lib.load_variant); the shipped libmvn_hip.so does not
+ * export this.  Spin limit of the training kernels' device-wide barrier, and phantom workgroups every barrier additionally
+ * waits for (> 0 forces the give-up path); negative arguments leave a setting unchanged. */
 void mvn_test_hooks(int64_t group_spin_limit, int32_t group_phantoms) {
-    if (group_spin_limit >= 0) g_group_spin_limit = (unsigned)group_spin_limit;
-    if (group_phantoms >= 0) g_group_phantoms = group_phantoms;
+    if (group_spin_limit >= 0) g_group_spin_limit.store((unsigned)group_spin_limit, std::memory_order_relaxed);
+    if (group_phantoms >= 0) g_group_phantoms.store(group_phantoms, std::memory_order_relaxed);
 }
+#endif
 
 int mvn_isi_awgn_transmit(const float *bits, int64_t ld_bits, int32_t K, const void *noise, int32_t noise_is_f64,
                           const double *h, int64_t Bh, double sigma, float *y, int64_t y_ld, int64_t B, int32_t T,

@@ -37,7 +37,7 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.mvn_version() == 4
+    assert lib.mvn_version() == 5
     assert lib.mvn_strerror(0) == b"ok"
     for code in (-1, -2, -3, -4, -5, -6, -7, -99):
         assert lib.mvn_strerror(code).startswith(b"mvn:")
@@ -84,6 +84,50 @@ def test_argument_validation_needs_no_device(lib):
     assert one > 0 and one % 256 == 0 and lib.mvn_vnet_train_trials_workspace_bytes(16, 136, 1, 7) == 7 * one
     assert lib.mvn_vnet_train_trials_workspace_bytes(16, 32, 1, 4) == lib.mvn_vnet_train_trials_workspace_bytes(16, 32, 1, 1) * 4
     assert lib.mvn_vnet_train_trials_workspace_bytes(64, 136, 1, 4) == 0
+
+
+def test_test_hooks_are_not_in_the_shipped_library(lib):
+    """mvn_test_hooks (forces the training kernels' barrier to give up) exists in the tests' -DMVN_TEST_HOOKS build only."""
+    import meta_viterbinet_amd as mvn
+
+    shipped = ctypes.CDLL(os.path.join(ROOT, "meta-viterbinet_amd", "libmvn_hip.so"))
+    assert not hasattr(shipped, "mvn_test_hooks")
+    assert "mvn_test_hooks" not in mvn._lib.SIGNATURES and "mvn_test_hooks" not in _declared_symbols()
+
+
+def test_train_kernel_name_validates(lib):
+    name = ctypes.create_string_buffer(96)
+    assert lib.mvn_vnet_train_kernel_name(3, 1, 136, 0, 16, 0, name, 96) == -1
+    assert lib.mvn_vnet_train_kernel_name(1, 1, 136, 0, 16, 0, name, 96) == -1  # a meta-learning step has W >= 1 support words
+    assert lib.mvn_vnet_train_kernel_name(0, 1, 136, 0, 64, 0, name, 96) == -2
+    assert lib.mvn_vnet_train_kernel_name(0, 1, 136, 0, 16, 0, None, 96) == -4
+    # without a workspace every form is one workgroup per trial; minibatch iterations always are
+    assert lib.mvn_vnet_train_kernel_name(0, 0, 136, 0, 16, 0, name, 96) == 0 and name.value == b"online_train_kernel<16, false> 1x1"
+    assert lib.mvn_vnet_train_kernel_name(0, 7, 136, 32, 16, 1 << 30, name, 96) == 0 and name.value == b"online_train_kernel<16, true> 1x7"
+    assert lib.mvn_vnet_train_kernel_name(2, 3, 136, 1, 32, 0, name, 96) == 0 and name.value == b"maml_train_kernel<0, true> 1x3"
+    assert lib.mvn_vnet_train_kernel_name(2, 0, 136, 1, 32, 0, name, 96) == 0 and name.value == b"maml_train_kernel<32, false> 1x1"
+
+
+def test_host_threads_under_tsan():
+    """The library's process-global state (MVN_* switch table, dynamic-LDS opt-in table, CU-count cache) is safe to use from
+    several host threads: csrc/mvn_hip.hip's HOST code is built with -fsanitize=thread together with a driver that calls
+    argument-validating and dispatch-query entry points from eight threads while one re-reads the switches
+    (tests/native/tsan_driver.cpp).  No device needed, none used."""
+    import subprocess
+    import tempfile
+
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "tsan_driver")
+        build = subprocess.run([hipcc, "--offload-arch=gfx950", "--offload-host-only", "-fsanitize=thread", "-O1", "-g", "-std=c++17",
+                                "-ffp-contract=off", "-x", "hip", os.path.join(ROOT, "meta-viterbinet_amd", "csrc", "mvn_hip.hip"),
+                                "-x", "c++", os.path.join(ROOT, "tests", "native", "tsan_driver.cpp"), "-o", exe, "-pthread",
+                                # host-only: the device code object the registration stub points at does not exist (never used)
+                                "-Wl,--unresolved-symbols=ignore-all"], capture_output=True, text=True)
+        assert build.returncode == 0, build.stderr[-2000:]
+        run = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, TSAN_OPTIONS="exitcode=66 halt_on_error=0"))
+    assert "ThreadSanitizer" not in run.stderr, run.stderr[:3000]
+    assert run.returncode == 0 and "0 wrong answers" in run.stdout, (run.returncode, run.stdout, run.stderr[-500:])
 
 
 def test_trial_descriptor_layout_matches_the_header():

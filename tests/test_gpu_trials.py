@@ -149,18 +149,67 @@ FLOWS = {
 }
 
 
+MANY_TRIALS_FLOWS = {  # the configs[4] flow with short iteration counts, for the 176-trial test
+    "meta_viterbinet_short": dict(self_supervised=True, self_supervised_iterations=5, online_meta=True, meta_train_iterations=2,
+                                  meta_j_num=3, meta_subframes=5, meta_style_online_training=True),
+}
+
+
+def _train_kernel_name(kind, R, T, M_or_W, S, ws_bytes):
+    name = ctypes.create_string_buffer(128)
+    assert mvn._lib.load().mvn_vnet_train_kernel_name(kind, R, T, M_or_W, S, ws_bytes, name, 128) == 0
+    return name.value.decode()
+
+
+# The launcher's forms of the trial-batched training kernels (mvn_hip.hip: plan_online_groups / plan_maml_groups):
+#   chunked   -- one workgroup per 32-sample chunk AND trial: *_train_groups_kernel<SC, true> (the launcher's choice for few trials)
+#   per_trial -- one workgroup per trial: online_train_kernel<SC, true> with M = 0, maml_train_kernel<SC, true> -- the launcher's
+#                choice from ~154 trials on, i.e. what bench.py times at 256 trials; forced here with MVN_TRAIN_GROUPS=0
+FORMS = {"chunked": "1", "per_trial": "0"}
+_SEQUENTIAL = {}
+
+
+def _sequential_runs(golden, dev, flow, R, N, K, nsym, sub, snrs, w, msg, rx, seed0):
+    """The R trials one after the other through harness.eval_by_word (the single-trial entry points), once per flow."""
+    key = (flow, R, N)
+    if key not in _SEQUENTIAL:
+        out = []
+        for r in range(R):
+            det = _vnet_with(w[r], K + 8 * nsym, dev)
+            tr = mvn.OnlineTrainer(det, 4)
+            ser = mvn.eval_by_word(det, msg[r], rx[r], snrs[r], 0.2, nsym, sub, online_trainer=tr,
+                                   meta_detector=mvn.META_VNETDetector(16, {"train": K + 8 * nsym, "val": K + 8 * nsym}),
+                                   draws=TrialDraws(seed0 + r, dev), **{**FLOWS, **MANY_TRIALS_FLOWS}[flow])
+            out.append((ser, [p.detach().clone() for p in det.parameters()], tr.exp_avg.clone(), tr.exp_avg_sq.clone(), tr.step))
+        _SEQUENTIAL[key] = out
+    return _SEQUENTIAL[key]
+
+
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("form", sorted(FORMS))
 @pytest.mark.parametrize("flow", sorted(FLOWS))
-def test_batched_trials_equal_sequential_runs(golden, dev, flow):
+def test_batched_trials_equal_sequential_runs(golden, dev, monkeypatch, flow, form):
     """R trials stepping together (trials.eval_by_word_batched: one step launch, one sync, one launch sequence per training
     kind and block for ALL trials) against the same trials run one after the other through harness.eval_by_word with the
     same per-trial draws: ser_by_word, the final weights, the saved weights' effect, both Adam moments and the step counts
-    are IDENTICAL per trial.  Trials sit at different SNRs, so they push, train and meta-learn at different blocks."""
+    are IDENTICAL per trial.  Trials sit at different SNRs, so they push, train and meta-learn at different blocks.
+    Both forms of the trial kernels (FORMS) against the same sequential runs, which use the default single-trial kernels."""
     R, N, K, nsym, sub = 7, 58, 120, 2, 25
+    T = K + 8 * nsym
     kw = FLOWS[flow]
     snrs = [6.0, 7.0, 8.0, 9.0, 10.0, 11.0, 12.0]
     w = _trial_weights(golden, R, seed=3)
     msg, rx = _words(dev, R, N, K, nsym, snrs, seed=11)
+    monkeypatch.delenv("MVN_TRAIN_GROUPS", raising=False)
+    seq = _sequential_runs(golden, dev, flow, R, N, K, nsym, sub, snrs, w, msg, rx, 100)
+    monkeypatch.setenv("MVN_TRAIN_GROUPS", FORMS[form])
+    W = kw.get("window_size", 1)
+    ws_bytes = int(mvn._lib.load().mvn_vnet_train_trials_workspace_bytes(16, T, W, R))
+    tag = "_groups_kernel<16, true>" if form == "chunked" else "_kernel<16, true> 1x"
+    if kw.get("meta_style_online_training"):  # full-word iterations (minibatch iterations are one chunk: one form only)
+        assert tag in _train_kernel_name(0, R, T, 0, 16, ws_bytes)
+    if kw.get("online_meta"):
+        assert tag in _train_kernel_name(2 if kw.get("MAML", True) else 1, R, T, W, 16, ws_bytes)
     bank = TrialBank(w, 16, 4, dev)
     rec = {}
     ser_b = eval_by_word_batched(bank, msg, rx, nsym, sub, [TrialDraws(100 + r, dev) for r in range(R)], record=rec, **kw)
@@ -171,16 +220,12 @@ def test_batched_trials_equal_sequential_runs(golden, dev, flow):
     assert np.array_equal(bank3.step, bank.step)
     trained_blocks = 0
     for r in range(R):
-        det = _vnet_with(w[r], K + 8 * nsym, dev)
-        tr = mvn.OnlineTrainer(det, 4)
-        ser = mvn.eval_by_word(det, msg[r], rx[r], snrs[r], 0.2, nsym, sub, online_trainer=tr,
-                               meta_detector=mvn.META_VNETDetector(16, {"train": K + 8 * nsym, "val": K + 8 * nsym}),
-                               draws=TrialDraws(100 + r, dev), **kw)
+        ser, wr, m, v, step = seq[r]
         assert np.array_equal(ser, ser_b[r]), (flow, r)
-        for a, b in zip(det.parameters(), bank.weights(r)):
-            assert torch.equal(a.detach(), b), (flow, r)
-        assert torch.equal(tr.exp_avg, bank.exp_avg[r]) and torch.equal(tr.exp_avg_sq, bank.exp_avg_sq[r]), (flow, r)
-        assert tr.step == int(bank.step[r]), (flow, r)
+        for a, b in zip(wr, bank.weights(r)):
+            assert torch.equal(a, b), (flow, r)
+        assert torch.equal(m, bank.exp_avg[r]) and torch.equal(v, bank.exp_avg_sq[r]), (flow, r)
+        assert step == int(bank.step[r]), (flow, r)
         trained_blocks += int(rec["trained"][r].sum() + rec["meta"][r].sum())
     assert trained_blocks > R  # the flows did train
     assert len({tuple(row) for row in ser_b}) > 1  # and the trials are not copies of each other
@@ -189,16 +234,59 @@ def test_batched_trials_equal_sequential_runs(golden, dev, flow):
         assert per_trial.min() < per_trial.max()  # different trials trained on different blocks
 
 
-def _hooks(spin_limit, phantoms):
-    fn = mvn._lib.load().mvn_test_hooks
-    fn.restype, fn.argtypes = None, [ctypes.c_int64, ctypes.c_int32]
-    fn(spin_limit, phantoms)
+@pytest.mark.timeout(900)
+def test_many_trials_take_the_one_workgroup_per_trial_form_by_themselves(golden, dev, monkeypatch):
+    """The launcher's OWN choice at the trial counts bench.py quotes (256 per GPU): from ~154 training trials on, one
+    workgroup per trial -- online_train_kernel<16, true> on whole words and maml_train_kernel<16, true> -- instead of one per
+    chunk and trial.  176 trials x 12 blocks of the configs[4] flow (short iteration counts), no switch set: the kernel the
+    library names for the steps' active-trial counts is that form, and every trial is bit-identical to its sequential run."""
+    R, N, K, nsym, sub = 176, 12, 120, 2, 25
+    T = K + 8 * nsym
+    flow = "meta_viterbinet_short"
+    kw = MANY_TRIALS_FLOWS[flow]
+    monkeypatch.delenv("MVN_TRAIN_GROUPS", raising=False)
+    snrs = [10.0 + 0.0125 * r for r in range(R)]
+    w = _trial_weights(golden, R, seed=8, spread=0.02)
+    msg, rx = _words(dev, R, N, K, nsym, snrs, seed=13)
+    bank = TrialBank(w, 16, 4, dev)
+    rec = {}
+    ser_b = eval_by_word_batched(bank, msg, rx, nsym, sub, [TrialDraws(500 + r, dev) for r in range(R)], record=rec, **kw)
+    ws_bytes = int(mvn._lib.load().mvn_vnet_train_trials_workspace_bytes(16, T, 1, R))
+    kernel = lambda kind, active, W: " ".join(_train_kernel_name(kind, int(active), T, W, 16, ws_bytes).split(" ")[:2])  # noqa: E731
+    online_names = {kernel(0, a, 0) for a in rec["trained"].sum(axis=0) if a}  # per block: the trials that trained together
+    meta_names = {kernel(2, a, 1) for a in rec["meta"].sum(axis=0) if a}
+    assert "online_train_kernel<16, true>" in online_names, online_names
+    assert "maml_train_kernel<16, true>" in meta_names, meta_names
+    seq = _sequential_runs(golden, dev, flow, R, N, K, nsym, sub, snrs, w, msg, rx, 500)
+    for r in range(R):
+        ser, wr, m, v, step = seq[r]
+        assert np.array_equal(ser, ser_b[r]), r
+        for a, b in zip(wr, bank.weights(r)):
+            assert torch.equal(a, b), r
+        assert torch.equal(m, bank.exp_avg[r]) and torch.equal(v, bank.exp_avg_sq[r]) and step == int(bank.step[r]), r
+    assert int(rec["meta"].sum()) > R and int(rec["trained"].sum()) > 5 * R
 
 
-def test_abandoned_group_barrier_is_reported_not_silent(golden, dev):
+@pytest.fixture
+def hooks_lib(monkeypatch):
+    """The -DMVN_TEST_HOOKS build of the library (libmvn_hip_hooks.so: same sources + mvn_test_hooks) in place of the
+    shipped one for the duration of a test."""
+    import __graft_entry__ as ge
+
+    lib = mvn._lib.load_variant(ge.build_hip_hooks())
+    lib.mvn_test_hooks.restype, lib.mvn_test_hooks.argtypes = None, [ctypes.c_int64, ctypes.c_int32]
+    mvn._lib.load()
+    monkeypatch.setattr(mvn._lib, "_lib", lib)
+    lib.mvn_reload_switches()
+    yield lib
+    lib.mvn_test_hooks(1 << 22, 0)
+
+
+def test_abandoned_group_barrier_is_reported_not_silent(golden, dev, hooks_lib):
     """A training launch whose device-wide barrier cannot complete (forced here: every barrier waits for one workgroup that
     does not exist, with a short spin limit) must not hand back NaN weights with rc == 0 and nothing else: the status word
     is set, OnlineTrainer.check_status() / harness.eval_by_word / trials.eval_by_word_batched raise MvnError."""
+    _hooks = hooks_lib.mvn_test_hooks
     g7 = golden("g7_by_word")
     w = [g7[f"w{i}"] for i in range(6)]
     T = 136
@@ -272,14 +360,16 @@ def test_two_training_launches_in_flight(golden, dev):
     assert all(bool(torch.isfinite(a).all()) for a in serial)
 
 
+@pytest.mark.parametrize("form", sorted(FORMS))
 @pytest.mark.parametrize("S,T", [(4, 100), (32, 136), (8, 40)])
-def test_trial_entry_points_for_other_state_counts(dev, S, T):
+def test_trial_entry_points_for_other_state_counts(dev, monkeypatch, S, T, form):
     """mvn_vnet_online_train_trials_f32 / mvn_vnet_maml_train_trials_f32 through hand-filled descriptors (what a C caller
     does) for S != 16 -- the run-time-S instantiations of the trial kernels -- with trials of different iteration counts,
     one inactive trial, separate input / output / second-copy weights: per trial bit-identical to mvn.OnlineTrainer (the
     single-trial entry points), minibatch and full-word iterations, second-order meta-learning steps."""
     from meta_viterbinet_amd import trials as tr_mod
 
+    monkeypatch.setenv("MVN_TRAIN_GROUPS", FORMS[form])
     lib, L, R = mvn._lib.load(), int(np.log2(S)), 4
     rng = np.random.RandomState(S)
     gen = torch.Generator(device=dev).manual_seed(S)
@@ -323,6 +413,9 @@ def test_trial_entry_points_for_other_state_counts(dev, S, T):
         dd = torch.from_numpy(d.view(np.uint8)).to(dev)
         nb = int(lib.mvn_vnet_train_trials_workspace_bytes(S, T, 1, R))
         wsb = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+        if mode != "minibatch":  # the run-time-S instantiations, in the form asked for
+            named = _train_kernel_name(2 if mode == "maml" else 0, R, T, 1 if mode == "maml" else 0, S, nb)
+            assert ("_groups_kernel<0, true>" if form == "chunked" else "_kernel<0, true> 1x") in named, named  # (every T here is > 32)
         if mode == "maml":
             rc = lib.mvn_vnet_maml_train_trials_f32(mvn._lib.ptr(dd), R, T, 1, 0.1, 1, 1e-3, 0.9, 0.999, 1e-8, S, mvn._lib.ptr(wsb), nb,
                                                     mvn._lib.current_stream(dev))
