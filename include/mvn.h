@@ -54,7 +54,7 @@ typedef void *mvn_stream_t; /* hipStream_t */
 
 #define MVN_E_BARRIER (-7)   /* (status words only) a training launch abandoned its device-wide barrier */
 
-#define MVN_ABI_VERSION 5 /* 5: + mvn_vnet_train_kernel_name; 4: + trial-batched training / by-word step, status words; 3: training with a workspace; 2: kernel-name queries */
+#define MVN_ABI_VERSION 5 /* 5: + mvn_vnet_train_kernel_name, mvn_va_byword_step_f32; 4: + trial-batched training / by-word step, status words; 3: training with a workspace; 2: kernel-name queries */
 
 /* ABI version of the loaded library (== MVN_ABI_VERSION). */
 int mvn_version(void);
@@ -302,6 +302,19 @@ int mvn_vnet_byword_step_f32(const float *rx, int64_t rx_ld, const float *tx, in
                              float *dec, int64_t dec_ld, float *msg, int64_t msg_ld, float *enc, int64_t enc_ld,
                              float *label_word, int64_t lw_ld, int32_t *labels, int64_t lab_ld, int32_t *nerr, int64_t R,
                              int32_t T, int32_t nsym, int32_t pilot, int32_t S, mvn_stream_t stream);
+
+/*
+ * The same block step for the classical Viterbi detector (the reference's eval_by_word takes any detector, trainer.py:295):
+ * dec = VADetector.forward(rx, 'val', snr, gamma, count) with the state priors given as in mvn_va_decode_f32 -- word r uses
+ * row r % Bp of state_priors [Bp, 16] (compute_state_priors, va_detector.py:42-50, of the word's channel) -- then exactly
+ * the codec, label word and trellis states of mvn_vnet_byword_step_f32; same outputs, same limits (16 states, T a multiple of
+ * 8, T <= 1024, nsym <= 8).  One wavefront per word.  Decisions are bit-identical to mvn_va_decode_f32, decoded / encoded
+ * words to mvn_rs_decode_bits_f32 / mvn_rs_encode_bits_f32.
+ */
+int mvn_va_byword_step_f32(const float *rx, int64_t rx_ld, const float *tx, int64_t tx_ld, const float *state_priors, int64_t Bp,
+                           float *dec, int64_t dec_ld, float *msg, int64_t msg_ld, float *enc, int64_t enc_ld, float *label_word,
+                           int64_t lw_ld, int32_t *labels, int64_t lab_ld, int32_t *nerr, int64_t R, int32_t T, int32_t nsym,
+                           int32_t pilot, int32_t S, mvn_stream_t stream);
 
 /* The MVN_* environment switches (A/B variants of the kernels) are read once per process; a caller that
  * changes them afterwards (the test-suite does) calls this to have them read again. */

@@ -50,6 +50,8 @@ SIGNATURES = {
     "mvn_vnet_train_kernel_name": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, ctypes.c_size_t, ctypes.c_char_p, _i32]),
     "mvn_vnet_byword_step_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64] + [_vp] * 6 + [ctypes.POINTER(ctypes.c_int64)] +
                                  [_vp, _i64] * 4 + [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "mvn_va_byword_step_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64] + [_vp, _i64] * 4 + [_vp, _i64, _vp, _i64, _i32, _i32,
+                                              _i32, _i32, _vp]),
     "mvn_reload_switches": (None, []),
     "mvn_isi_awgn_transmit": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _i64, ctypes.c_double, _vp, _i64, _i64,
                                              _i32, _i32, _vp]),

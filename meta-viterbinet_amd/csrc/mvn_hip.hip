@@ -1306,6 +1306,29 @@ int mvn_vnet_byword_step_f32(const float *rx, int64_t rx_ld, const float *tx, in
     return (int)hipGetLastError();
 }
 
+int mvn_va_byword_step_f32(const float *rx, int64_t rx_ld, const float *tx, int64_t tx_ld, const float *state_priors, int64_t Bp,
+                           float *dec, int64_t dec_ld, float *msg, int64_t msg_ld, float *enc, int64_t enc_ld, float *label_word,
+                           int64_t lw_ld, int32_t *labels, int64_t lab_ld, int32_t *nerr, int64_t R, int32_t T, int32_t nsym,
+                           int32_t pilot, int32_t S, mvn_stream_t stream) {
+    if (S != 16) return MVN_E_STATES;  // the fused step exists for the 16-state detectors
+    if (R < 0 || T < 8 || (T & 7) || T > kCoopMaxT || nsym < 1 || nsym > 8 || T / 8 <= nsym) return MVN_E_DIMS;
+    const int K = T - 8 * nsym;
+    if (rx_ld < T || tx_ld < K || (dec && dec_ld < T) || (msg && msg_ld < K) || (enc && enc_ld < T) ||
+        (label_word && lw_ld < T) || (labels && lab_ld < T))
+        return MVN_E_DIMS;
+    if (Bp < 1) return MVN_E_PRIORS;
+    if (R == 0) return MVN_OK;
+    if (!tx || (!pilot && (!rx || !state_priors))) return MVN_E_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (nsym <= 2)
+        hipLaunchKernelGGL((byword_step_va_kernel<2>), dim3((unsigned)R), dim3(64), 0, st, rx, rx_ld, tx, tx_ld, state_priors, Bp, dec,
+                           dec_ld, msg, msg_ld, enc, enc_ld, label_word, lw_ld, labels, lab_ld, nerr, T, nsym, pilot);
+    else
+        hipLaunchKernelGGL((byword_step_va_kernel<8>), dim3((unsigned)R), dim3(64), 0, st, rx, rx_ld, tx, tx_ld, state_priors, Bp, dec,
+                           dec_ld, msg, msg_ld, enc, enc_ld, label_word, lw_ld, labels, lab_ld, nerr, T, nsym, pilot);
+    return (int)hipGetLastError();
+}
+
 void mvn_reload_switches(void) { load_switches(); }
 
 #ifdef MVN_TEST_HOOKS

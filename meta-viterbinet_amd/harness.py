@@ -231,7 +231,7 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
             for count in range(N):
                 if count % subframes_in_frame != 0:
                     _byword_step(detector, rx[count:count + 1], tx[count:count + 1], n_symbols, False, nerr[count:count + 1],
-                                 outputs=False)
+                                 outputs=False, gamma=gamma, count=count if pass_count else None)
             e = nerr.cpu().numpy()
             data = np.arange(N) % subframes_in_frame != 0
             ser_by_word[data] = _metrics.ser_from_errors(e[data], K)  # the reference's value bit for bit (metrics.py:13-16)
@@ -281,7 +281,8 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
         pilot = count % subframes_in_frame == 0
         seen = {"count": count, "meta": None, "trained": False, "batch_idx": None} if observer is not None else None
         if fused:  # ONE launch: detect, RS decode, error count, re-encode (pilot: encode the known word)
-            detected_word, encoded_word = _byword_step(detector, received_word, transmitted_word, n_symbols, pilot, nerr1)
+            detected_word, encoded_word = _byword_step(detector, received_word, transmitted_word, n_symbols, pilot, nerr1,
+                                                       gamma=gamma, count=count if pass_count else None)
             ser = 0.0 if pilot else float(_metrics.ser_from_errors(int(nerr1.item()), K))  # calculate_error_rates (:301)
             if not pilot:
                 ser_by_word[count] = ser
@@ -308,9 +309,14 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
             if weights_init == "last_frame":  # meta_weights_init (:356-366)
                 copy_model(source_model=saved_detector, dest_model=detector)
             elif weights_init == "random":
-                for m in detector.net:
-                    if hasattr(m, "reset_parameters"):
-                        m.reset_parameters()
+                if draws is not None:  # this trial's own stream (what lets trials.eval_by_word_batched replay the run)
+                    with torch.no_grad():
+                        for p_, w_ in zip(detector.parameters(), draws.init_weights(detector.n_states)):
+                            p_.copy_(w_)
+                else:
+                    for m in detector.net:
+                        if hasattr(m, "reset_parameters"):
+                            m.reset_parameters()
                 online_trainer.reset_state()
             else:
                 with torch.no_grad():
@@ -331,14 +337,19 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
                 if graphed_meta and meta_step is None:  # captured once: one hipGraph replay per MAML step from here on
                     meta_step = GraphedMetaStep(detector, meta_detector, online_trainer, window_size, rx.shape[1], meta_lr,
                                                 MAML)
+                j_seen = []
                 for _ in range(meta_train_iterations):
                     j_hat_values = draw_j_hat(buffer_rx.shape[0] - 2)
+                    j_seen.append(j_hat_values)
                     for j_hat in j_hat_values:
                         if meta_step is not None:
                             meta_step(buffer_rx, buffer_tx, j_hat + support_idx + 1, j_hat + query_idx + 1)
                         else:
                             meta_train_loop(detector, meta_detector, online_trainer, buffer_rx, buffer_tx,
                                             j_hat + support_idx + 1, j_hat + query_idx + 1, meta_lr, MAML)
+                if seen is not None:
+                    j_all = torch.cat(j_seen)
+                    seen["meta"] = (j_all.reshape(-1, 1) + support_idx.reshape(1, -1) + 1, j_all + query_idx + 1)
             copy_model(source_model=detector, dest_model=saved_detector)
             if seen is not None and seen["meta"] is not None:
                 observer(dict(seen, stage="meta", detector=detector, saved_detector=saved_detector, buffer_rx=buffer_rx,
@@ -366,29 +377,45 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
 
 
 def _fused_step_applies(detector, rx: torch.Tensor, n_symbols: int, pass_count: bool) -> bool:
-    """mvn_vnet_byword_step_f32 serves a 16-state VNETDetector whose 'val' length is the word length (Q5), words of whole
-    bytes up to 1024 symbols and nsym <= 8; everything else takes the separate detect / RS / count launches."""
-    from .detectors import VNETDetector
+    """One launch per block step (mvn_vnet_byword_step_f32 / mvn_va_byword_step_f32) serves a 16-state VNETDetector or
+    VADetector whose 'val' length is the word length (Q5), words of whole bytes up to 1024 symbols and nsym <= 8; everything
+    else takes the separate detect / RS / count launches.  (pass_count: the reference passes the block number to the detector,
+    which is how VADetector picks the word's channel; ViterbiNet ignores it.)"""
+    from .detectors import VADetector, VNETDetector
 
     T = rx.shape[1]
-    return (isinstance(detector, VNETDetector) and detector.n_states == 16 and rx.is_cuda and not pass_count
-            and detector.transmission_lengths["val"] == T and T % 8 == 0 and 8 <= T <= 1024 and 1 <= n_symbols <= 8
-            and T // 8 > n_symbols)
+    if not (rx.is_cuda and getattr(detector, "n_states", None) == 16 and T % 8 == 0 and 8 <= T <= 1024 and 1 <= n_symbols <= 8 and T // 8 > n_symbols):
+        return False
+    if isinstance(detector, VNETDetector):
+        return not pass_count and detector.transmission_lengths["val"] == T
+    return isinstance(detector, VADetector) and detector.transmission_length == T
 
 
 def _byword_step(detector, received_word: torch.Tensor, transmitted_word: torch.Tensor, n_symbols: int, pilot: bool,
-                 nerr: torch.Tensor, outputs: bool = True):
+                 nerr: torch.Tensor, outputs: bool = True, gamma: float = None, count: int = None):
     """One block of eval_by_word in one launch (trainer.py:292-316): returns (detected_word, encoded_word) [1, T]; the
     block's bit-error count goes to nerr[0] (device int32).  On a pilot the detection is skipped (never used) and
-    detected_word is None.  outputs=False: the error count only (no words are stored, the re-encoding is skipped)."""
+    detected_word is None.  outputs=False: the error count only (no words are stored, the re-encoding is skipped).
+    gamma / count: what VADetector.forward takes to find the word's channel (count None: the detector's single table row)."""
     from . import _lib
+    from .detectors import VADetector
 
     rxw, txw = _lib.f32c(received_word), _lib.f32c(transmitted_word)
     T, K = rxw.shape[1], txw.shape[1]
     dev = rxw.device
-    w = detector._params()
     det = None if (pilot or not outputs) else torch.empty((1, T), dtype=torch.float32, device=dev)
     enc = torch.empty((1, T), dtype=torch.float32, device=dev) if outputs else None
+    if isinstance(detector, VADetector):
+        pri = detector._priors_table(rxw, gamma, "val", count)  # [W, 16] (one row when count is given)
+        if pri.shape[0] != 1:
+            raise RuntimeError(f"The size of tensor a (1) must match the size of tensor b ({pri.shape[0]}) at non-singleton dimension 0")
+        with _lib.on_device(dev):
+            rc = _lib.load().mvn_va_byword_step_f32(_lib.ptr(rxw), T, _lib.ptr(txw), K, _lib.ptr(pri), 1, _lib.ptr(det), T, None, K,
+                                                    _lib.ptr(enc), T, None, T, None, T, _lib.ptr(nerr), 1, T, n_symbols,
+                                                    1 if pilot else 0, 16, _lib.current_stream(dev))
+        _lib.check(rc, "mvn_va_byword_step_f32")
+        return det, enc
+    w = detector._params()
     with _lib.on_device(dev):
         rc = _lib.load().mvn_vnet_byword_step_f32(_lib.ptr(rxw), T, _lib.ptr(txw), K, *[_lib.ptr(_lib.f32c(p)) for p in w], None,
                                                   _lib.ptr(det), T, None, K, _lib.ptr(enc), T, None, T, None, T,

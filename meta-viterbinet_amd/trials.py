@@ -77,6 +77,20 @@ class TrialDraws:
             raise ValueError(f"TrialDraws was drawn for {self._shape}, asked for {shape}")
         return self._table[count]
 
+    def init_weights(self, n_states: int) -> List[torch.Tensor]:
+        """Freshly initialised ViterbiNet weights for meta_weights_init('random') (trainer.py:356-359 -> initialize_detector):
+        nn.Linear's default reset_parameters (kaiming_uniform(a = sqrt 5) = U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and
+        bias), layer by layer in parameters() order, from this trial's own stream (a host generator seeded by the trial's seed;
+        successive calls continue the stream).  Six CPU tensors."""
+        if not hasattr(self, "_init_gen"):
+            self._init_gen = torch.Generator().manual_seed((self.seed * 2654435761 + 12345) % (2 ** 63))
+        out = []
+        for fan_out, fan_in in ((HIDDEN1_SIZE, 1), (HIDDEN2_SIZE, HIDDEN1_SIZE), (n_states, HIDDEN2_SIZE)):
+            bound = 1.0 / np.sqrt(fan_in)
+            out.append(torch.empty(fan_out, fan_in).uniform_(-bound, bound, generator=self._init_gen))
+            out.append(torch.empty(fan_out).uniform_(-bound, bound, generator=self._init_gen))
+        return out
+
     def j_hat(self, high: int, size: int) -> np.ndarray:
         """np.unique(randint(0, high, size)): sorted distinct buffer positions, like torch.unique(torch.randint(...))."""
         return self.j_hat_update(high, 1, size)
@@ -95,7 +109,10 @@ class TrialBank:
     stacked device tensors; row r is trial r, a row holds the six arrays flat in parameters() order."""
 
     def __init__(self, weights: Sequence[Sequence], n_states: int, memory_length: int, device, lr: float = 0.001,
-                 betas=(0.9, 0.999), eps: float = 1e-8):
+                 betas=(0.9, 0.999), eps: float = 1e-8, optimizer_type: str = "Adam"):
+        if optimizer_type not in ("Adam", "RMSprop", "SGD"):  # deep_learning_setup (trainer.py:163-175)
+            raise NotImplementedError("No such optimizer implemented!!!")
+        self.optimizer_type = optimizer_type
         self.R = len(weights)
         self.n_states, self.memory_length = n_states, memory_length
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -149,6 +166,7 @@ class _BankRows:
     def __init__(self, bank: TrialBank, lo: int, hi: int):
         self.R = hi - lo
         self.n_states, self.memory_length, self.lr, self.betas, self.eps = bank.n_states, bank.memory_length, bank.lr, bank.betas, bank.eps
+        self.optimizer_type = bank.optimizer_type
         self.off, self.P = bank.off, bank.P
         self.theta, self.saved = bank.theta[lo:hi], bank.saved[lo:hi]
         self.exp_avg, self.exp_avg_sq = bank.exp_avg[lo:hi], bank.exp_avg_sq[lo:hi]
@@ -163,12 +181,21 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
                          window_size: int = 1, meta_train_iterations: int = 20, meta_j_num: int = 10, meta_subframes: int = 5,
                          meta_style_online_training: bool = False, train_minibatch_size: int = 32,
                          weights_init: str = "last_frame", meta_training_weights=None, record: Optional[dict] = None,
-                         cohorts: int = 1) -> np.ndarray:
-    """R trials of harness.eval_by_word (= Trainer.eval_by_word, trainer.py:267-354, buffer_empty=True, Adam) at once.
+                         cohorts: int = 1, initial_buffer=None) -> np.ndarray:
+    """R trials of harness.eval_by_word (= Trainer.eval_by_word, trainer.py:267-354) at once, with the reference's switches:
+    buffer_empty True / False, weights_init last_frame / random / meta_training, Adam on the GPU kernels (RMSprop / SGD: see
+    below).
     tx [R, N, K] message bits, rx [R, N, K + 8 n_symbols] received words (trial r = row r, its own SNR / channel / seed);
     bank: the trials' weights and optimizer state (updated in place); draws[r]: trial r's TrialDraws.
     Returns ser_by_word [R, N] (0 for pilots), row r equal to eval_by_word(..., draws=draws[r]) run alone.
     record: optional dict that receives 'nerr' [R, N], 'trained' [R, N] bool and 'meta' [R, N] bool.
+    initial_buffer = (tx_codewords, rx_words), each [W0, T] (shared) or [R, W0, T]: the reference's buffer_empty=False
+    (trainer.py:278-286) -- every trial's buffer starts with these W0 words and stays W0 long, each qualifying block pushing the
+    oldest out (:325-328).  weights_init='random' (meta_weights_init, :356-359): before every meta-learning update the trial's
+    weights are re-initialised from ITS OWN stream (TrialDraws.init_weights) and its optimizer state reset.
+    bank.optimizer_type 'RMSprop' / 'SGD' (deep_learning_setup, :163-175): the training kernels implement Adam, the reference's
+    default; the other two optimizers run trial after trial through harness.eval_by_word on stock autograd -- same results as
+    calling it yourself, no batching.
     cohorts > 1: the trials are split into that many groups that step ALTERNATELY on the same stream: while the GPU works
     through one group's training launches the host takes the decisions and fills the descriptors of the next (the host
     work of a step can only start after the step's sync).  Same launches per trial, same results."""
@@ -178,6 +205,21 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
     ser_by_word = np.zeros((R, N))
     if record is not None:
         record.update(nerr=np.zeros((R, N), np.int64), trained=np.zeros((R, N), bool), meta=np.zeros((R, N), bool))
+    if weights_init not in ("last_frame", "random", "meta_training"):
+        raise ValueError("No such weights init!!!")
+    if initial_buffer is not None:  # (tx codewords, rx words), shared by the trials or one set per trial
+        ib = [t.to(device=rx.device, dtype=torch.float32) for t in initial_buffer]
+        ib = [t.unsqueeze(0).expand(R, -1, -1) if t.dim() == 2 else t for t in ib]
+        if ib[0].shape != ib[1].shape or ib[0].shape[0] != R or ib[0].shape[2] != rx.shape[2]:
+            raise ValueError("initial_buffer = (tx_codewords, rx_words), each [W0, T] or [R, W0, T]")
+        initial_buffer = ib
+    if bank.optimizer_type != "Adam":
+        return _one_trial_at_a_time(bank, tx, rx, n_symbols, subframes_in_frame, draws, ser_by_word, record, initial_buffer,
+                                    dict(self_supervised=self_supervised, self_supervised_iterations=self_supervised_iterations,
+                                         ser_thresh=ser_thresh, online_meta=online_meta, meta_lr=meta_lr, MAML=MAML, window_size=window_size,
+                                         meta_train_iterations=meta_train_iterations, meta_j_num=meta_j_num, meta_subframes=meta_subframes,
+                                         meta_style_online_training=meta_style_online_training, weights_init=weights_init,
+                                         meta_training_weights=meta_training_weights), train_minibatch_size)
     cohorts = max(1, min(int(cohorts), R))
     bounds = [(c * R) // cohorts for c in range(cohorts + 1)]
     gens = []
@@ -186,7 +228,8 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
         gens.append(_cohort_steps(_BankRows(bank, lo, hi), tx[lo:hi], rx[lo:hi], n_symbols, subframes_in_frame, draws[lo:hi],
                                   ser_by_word[lo:hi], rec, self_supervised, self_supervised_iterations, ser_thresh, online_meta,
                                   meta_lr, MAML, window_size, meta_train_iterations, meta_j_num, meta_subframes,
-                                  meta_style_online_training, train_minibatch_size, weights_init, meta_training_weights))
+                                  meta_style_online_training, train_minibatch_size, weights_init, meta_training_weights,
+                                  None if initial_buffer is None else [t[lo:hi] for t in initial_buffer]))
     with _lib.on_device(rx.device):
         waiting = [next(g) for g in gens]  # every cohort has enqueued its first step and says which event ends it
         while gens:
@@ -201,15 +244,55 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
     return ser_by_word
 
 
+def _one_trial_at_a_time(bank, tx, rx, n_symbols, subframes_in_frame, draws, ser_by_word, record, initial_buffer, kw,
+                         train_minibatch_size):
+    """The trials of a bank whose optimizer the training kernels do not implement (RMSprop, SGD), one after the other through
+    harness.eval_by_word (stock autograd); weights, saved weights, optimizer state and step counts go back into the bank."""
+    from .detectors import META_VNETDetector, VNETDetector
+    from .harness import eval_by_word
+    from .online import OnlineTrainer
+
+    T = rx.shape[2]
+    for r in range(bank.R):
+        det = VNETDetector(bank.n_states, {"train": T, "val": T}).to(bank.device)
+        with torch.no_grad():
+            for p_, a in zip(det.parameters(), bank.weights(r)):
+                p_.copy_(a)
+        tr = OnlineTrainer(det, bank.memory_length, lr=bank.lr, betas=bank.betas, eps=bank.eps, train_minibatch_size=train_minibatch_size,
+                           optimizer_type=bank.optimizer_type)
+        tr.exp_avg.copy_(bank.exp_avg[r])
+        tr.exp_avg_sq.copy_(bank.exp_avg_sq[r])
+        tr.step = int(bank.step[r])
+        last = {}
+
+        def observer(seen, last=last):
+            last.update(seen)
+            if record is not None and seen["stage"] == "end":
+                record["trained"][r, seen["count"]] = seen["trained"]
+                record["meta"][r, seen["count"]] = seen["meta"] is not None
+
+        ser_by_word[r] = eval_by_word(det, tx[r], rx[r], 0.0, 0.0, n_symbols, subframes_in_frame, online_trainer=tr,
+                                      meta_detector=META_VNETDetector(bank.n_states, {"train": T, "val": T}), draws=draws[r],
+                                      initial_buffer=None if initial_buffer is None else (initial_buffer[0][r], initial_buffer[1][r]),
+                                      observer=observer, **kw)
+        with torch.no_grad():
+            bank.theta[r].copy_(torch.cat([p_.detach().reshape(-1) for p_ in det.parameters()]))
+            saved = last.get("saved_detector")
+            bank.saved[r].copy_(torch.cat([p_.detach().reshape(-1) for p_ in (saved if saved is not None else det).parameters()]))
+            bank.exp_avg[r].copy_(tr.exp_avg)
+            bank.exp_avg_sq[r].copy_(tr.exp_avg_sq)
+        bank.step[r] = tr.step
+    return ser_by_word
+
+
 def _cohort_steps(bank, tx, rx, n_symbols, subframes_in_frame, draws, ser_by_word, record, self_supervised,
                   self_supervised_iterations, ser_thresh, online_meta, meta_lr, MAML, window_size, meta_train_iterations, meta_j_num,
-                  meta_subframes, meta_style_online_training, train_minibatch_size, weights_init, meta_training_weights):
+                  meta_subframes, meta_style_online_training, train_minibatch_size, weights_init, meta_training_weights,
+                  initial_buffer=None):
     """One group of trials stepping through its blocks: a generator that enqueues a step's GPU work and yields the event the
     host has to wait for before it can decide what the trials do next (eval_by_word_batched drives one or more of these)."""
     if bank.n_states != 16:
         raise NotImplementedError("the batched evaluation runs the 16-state kernels (mvn_vnet_byword_step_f32)")
-    if weights_init not in ("last_frame", "meta_training"):
-        raise NotImplementedError("weights_init='random' re-initialises one detector at a time: use harness.eval_by_word")
     _lib.require_gpu_tensor(rx, "rx")
     lib = _lib.load()
     dev = rx.device
@@ -224,7 +307,15 @@ def _cohort_steps(bank, tx, rx, n_symbols, subframes_in_frame, draws, ser_by_wor
     full_word = meta_style_online_training
     M = 0 if full_word else train_minibatch_size
 
-    labels = torch.zeros((R, N, T), dtype=torch.int32, device=dev)  # calculate_states of every block's label word
+    # A trial's words: the W0 words its buffer starts with (buffer_empty=False), then its N blocks; word number = position here
+    W0 = 0 if initial_buffer is None else int(initial_buffer[0].shape[1])
+    NA = W0 + N
+    labels = torch.zeros((R, NA, T), dtype=torch.int32, device=dev)  # calculate_states of every word's label word
+    if W0:
+        from .trellis import calculate_states
+
+        rx = torch.cat([initial_buffer[1].to(dev), rx], dim=1).contiguous()
+        labels[:, :W0] = calculate_states(bank.memory_length, initial_buffer[0].to(dev).reshape(R * W0, T)).reshape(R, W0, T).to(torch.int32)
     sync_dev = torch.zeros(2 * R, dtype=torch.int32, device=dev)     # [0:R] bit errors of the step, [R:2R] training status
     sync_host = torch.zeros(2 * R, dtype=torch.int32).pin_memory()
     nerr_np, status_np = sync_host.numpy()[:R], sync_host.numpy()[R:]
@@ -241,13 +332,18 @@ def _cohort_steps(bank, tx, rx, n_symbols, subframes_in_frame, draws, ser_by_wor
     m_p = np.uint64(bank.exp_avg.data_ptr()) + np.arange(R, dtype=np.uint64) * np.uint64(4 * bank.P)
     v_p = np.uint64(bank.exp_avg_sq.data_ptr()) + np.arange(R, dtype=np.uint64) * np.uint64(4 * bank.P)
     status_p = np.uint64(sync_dev.data_ptr()) + np.uint64(4) * (np.uint64(R) + np.arange(R, dtype=np.uint64))
-    rx_p = np.uint64(rx.data_ptr()) + np.arange(R, dtype=np.uint64) * np.uint64(4 * N * T)
-    lab_p = np.uint64(labels.data_ptr()) + np.arange(R, dtype=np.uint64) * np.uint64(4 * N * T)
+    rx_p = np.uint64(rx.data_ptr()) + np.arange(R, dtype=np.uint64) * np.uint64(4 * NA * T)
+    lab_p = np.uint64(labels.data_ptr()) + np.arange(R, dtype=np.uint64) * np.uint64(4 * NA * T)
     if weights_init == "meta_training":
         if meta_training_weights is None:
             raise ValueError("weights_init='meta_training' needs meta_training_weights (six arrays in parameters() order)")
         init_bank = TrialBank([meta_training_weights], S, bank.memory_length, dev)
         init_p = np.repeat(init_bank.pointers(init_bank.theta), R, axis=0)
+    elif weights_init == "random":  # a row of fresh weights per trial, refilled from the trial's stream before every update
+        init_host = torch.empty((R, bank.P), dtype=torch.float32).pin_memory()
+        init_dev = torch.empty((R, bank.P), dtype=torch.float32, device=dev)
+        init_p = (np.uint64(init_dev.data_ptr()) + np.arange(R, dtype=np.uint64)[:, None] * np.uint64(4 * bank.P)
+                  + (bank.off[:6].astype(np.uint64) * np.uint64(4))[None, :])
     sup_off = np.arange(-W, 0)
     table_p = None
     w_stride = (ctypes.c_int64 * 6)(*([bank.P] * 6))
@@ -255,15 +351,15 @@ def _cohort_steps(bank, tx, rx, n_symbols, subframes_in_frame, draws, ser_by_wor
     stream = _lib.current_stream(dev)
     ts = torch.cuda.current_stream(dev)
 
-    buffers: List[List[int]] = [[] for _ in range(R)]  # trial r's buffer: the block numbers it holds, oldest first
+    buffers: List[List[int]] = [list(range(W0)) for _ in range(R)]  # trial r's buffer: the word numbers it holds, oldest first
     tables = None
     done = torch.cuda.Event()  # (the driver holds the device guard)
     for count in range(N):
         pilot = 1 if count % subframes_in_frame == 0 else 0
-        rc = lib.mvn_vnet_byword_step_f32(ctypes.c_void_p(rx.data_ptr() + 4 * count * T), N * T,
+        rc = lib.mvn_vnet_byword_step_f32(ctypes.c_void_p(rx.data_ptr() + 4 * (W0 + count) * T), NA * T,
                                           ctypes.c_void_p(tx.data_ptr() + 4 * count * K), N * K, *wp, w_stride,
                                           None, T, None, K, None, T, None, T,
-                                          ctypes.c_void_p(labels.data_ptr() + 4 * count * T), N * T,
+                                          ctypes.c_void_p(labels.data_ptr() + 4 * (W0 + count) * T), NA * T,
                                           ctypes.c_void_p(sync_dev.data_ptr()), R, T, n_symbols, pilot, S, stream)
         _lib.check(rc, "mvn_vnet_byword_step_f32")
         sync_host.copy_(sync_dev, non_blocking=True)
@@ -274,9 +370,11 @@ def _cohort_steps(bank, tx, rx, n_symbols, subframes_in_frame, draws, ser_by_wor
         ser = ser_from_errors(nerr_np, K)  # the reference's value bit for bit (metrics.py:13-16)
         if not pilot:
             ser_by_word[:, count] = ser
-        push = ser <= ser_thresh  # trainer.py:319-324 (buffer_empty=True: the buffer only grows)
+        push = ser <= ser_thresh  # trainer.py:319-324
         for r in np.flatnonzero(push):
-            buffers[r].append(count)
+            buffers[r].append(W0 + count)
+            if W0:  # buffer_empty=False: a window of fixed length, the oldest word leaves (:325-328)
+                del buffers[r][0]
         if record is not None:
             record["nerr"][:, count] = nerr_np
         # ---- online meta-learning (trainer.py:331-343): restart from the saved weights, all steps in one launch
@@ -298,6 +396,14 @@ def _cohort_steps(bank, tx, rx, n_symbols, subframes_in_frame, draws, ser_by_wor
                     if record is not None:
                         record["meta"][r, count] = True
                 a = np.asarray(act)
+                if weights_init == "random":  # meta_weights_init('random'): fresh weights, fresh optimizer (trainer.py:356-359)
+                    for r in act:
+                        init_host[r].copy_(torch.cat([t.reshape(-1) for t in draws[r].init_weights(S)]))
+                    init_dev.copy_(init_host, non_blocking=True)  # (rewritten only after this step's sync, which follows the copy)
+                    a_dev = torch.as_tensor(a, device=dev)
+                    bank.exp_avg.index_fill_(0, a_dev, 0.0)
+                    bank.exp_avg_sq.index_fill_(0, a_dev, 0.0)
+                    bank.step[a] = 0
                 d = d_meta[:len(act)]
                 d["y"], d["labels"] = rx_p[a], lab_p[a]
                 d["idx"] = np.uint64(idx.dev.data_ptr()) + (4 * offs).astype(np.uint64)
@@ -322,8 +428,8 @@ def _cohort_steps(bank, tx, rx, n_symbols, subframes_in_frame, draws, ser_by_wor
                 tables = [draws[r]._table for r in range(R)]
                 table_p = np.array([t.data_ptr() for t in tables], dtype=np.uint64)
             d = d_onl[:len(act)]
-            d["y"] = rx_p[act] + np.uint64(4 * count * T)
-            d["labels"] = lab_p[act] + np.uint64(4 * count * T)
+            d["y"] = rx_p[act] + np.uint64(4 * (W0 + count) * T)
+            d["labels"] = lab_p[act] + np.uint64(4 * (W0 + count) * T)
             d["idx"] = table_p[act] + np.uint64(4 * count * self_supervised_iterations * M) if M else 0
             d["query_idx"] = 0
             d["w_in"] = saved_p[act] if meta_style_online_training else theta_p[act]  # metavnet_trainer.py:59

@@ -1,5 +1,5 @@
-// Host-side thread-safety check of libmvn_hip's process-global state (tests/test_abi.py::test_host_threads_under_tsan).
-// Built together with csrc/mvn_hip.hip, host code only, under -fsanitize=thread; needs no GPU: eight threads call entry
+// Host-side thread-safety check of libmvn_hip's process-global state (tests/test_tsan_host.py::test_host_threads_under_tsan).
+// Built together with csrc/mvn_hip.hip, host code only, under the host ThreadSanitizer; needs no GPU: eight threads call entry
 // points that validate their arguments, query the dispatcher (the MVN_* switch table, the CU-count cache) and ask for the
 // dynamic-LDS opt-in table, while one of them keeps re-reading the switches.  ThreadSanitizer reports any unsynchronised
 // access (exit code 66); the test also checks that the answers are the single-threaded ones.

@@ -688,8 +688,10 @@ def test_eval_by_word_loop_va_golden(golden, dev, coef):
     det = mvn.VADetector(16, L, T, frames * sub, "ISI_AWGN", 0, bool(fading), ttype, {"train": "time_decay", "val": coef})
     y = torch.tensor(g[f"{coef}_y"], device=dev)
     tx = torch.tensor(g[f"{coef}_tx"].astype(np.float32), device=dev)
-    ser = mvn.eval_by_word(det, tx, y, snr, 0.2, nsym, sub, pass_count=True)
+    ser = mvn.eval_by_word(det, tx, y, snr, 0.2, nsym, sub, pass_count=True)  # one mvn_va_byword_step_f32 launch per block
     assert np.array_equal(ser, g[f"{coef}_ser_by_word"])  # the reference's floats, bit for bit
+    ser4 = mvn.eval_by_word(det, tx, y, snr, 0.2, nsym, sub, pass_count=True, fused_step=False)  # detect, RS decode, count: separate launches
+    assert np.array_equal(ser4, g[f"{coef}_ser_by_word"])
 
 
 def test_eval_by_word_self_supervised_tracks_channel(golden, dev):

@@ -277,11 +277,14 @@ def _replay(dev, w0, msg, rx, flow_kw, iterations, meta_lr=0.1, MAML=True, strid
                 where = f"block {rec['count']} ({rec['stage']}) iteration {it} (Adam step {cur['step'] + 1})"
                 if r <= 1.0:
                     out["referee_runs"] += 1
-                    out["referee_worst"] = max(out["referee_worst"], r_h)
-                    assert _explained(r_h, r_t), f"{where}: against float64 HIP is at {r_h:.2f}, torch at {r_t:.2f} of the tolerance"
-                elif _explained(r_h, r_t):  # one iteration's rounding above the tolerance, in both fp32 implementations alike
-                    out["noisy"].append((rec["count"], rec["stage"], it, round(r, 2), round(r_h, 2), round(r_t, 2)))
-                else:  # not rounding: a ReLU derivative decided by summation order, or an error -- the assignments decide
+                if _explained(r_h, r_t):
+                    if r <= 1.0:
+                        out["referee_worst"] = max(out["referee_worst"], r_h)
+                    else:  # one iteration's rounding above the tolerance, in both fp32 implementations alike
+                        out["noisy"].append((rec["count"], rec["stage"], it, round(r, 2), round(r_h, 2), round(r_t, 2)))
+                else:
+                    # not rounding: a ReLU derivative decided by summation order -- HIP against torch (r > 1), or both fp32
+                    # implementations alike against float64 (seen unprovoked) -- or an error: the assignments decide
                     try:
                         n_near, best = _decide(run64, z2s, cur["m"], hip, t32, dv)
                     except AssertionError as e:
@@ -290,7 +293,7 @@ def _replay(dev, w0, msg, rx, flow_kw, iterations, meta_lr=0.1, MAML=True, strid
                     assert _explained(*best), (f"{where}: HIP and torch differ by {r:.1f} x the tolerance {parts}; {n_near} near-zero "
                                                f"pre-activation(s), but the best float64 assignments leave HIP at {best[0]:.2f} and torch "
                                                f"at {best[1]:.2f} of the tolerance")
-                    out["crossings"].append((rec["count"], rec["stage"], it, round(r, 1), n_near))
+                    out["crossings"].append((rec["count"], rec["stage"], it, round(max(r, r_h), 1), n_near))
         # the chain of n = 1 launches against the state the flow's own launch (all n_all iterations at once) left behind
         chain_w = _flat(det_k.parameters())
         exact = (torch.equal(chain_w, _flat(st["saved"] if is_meta else st["w"])) and torch.equal(tr_k.exp_avg, st["m"])

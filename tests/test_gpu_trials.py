@@ -115,6 +115,52 @@ def test_byword_step_equals_the_separate_launches(golden, dev, R, K, nsym, snr):
     assert torch.equal(shared["dec"], _vnet_with(w[0], T, dev)(rx, "val"))
 
 
+@pytest.mark.parametrize("R,K,nsym,snr,Bp", [(1, 120, 2, 9.0, 1), (24, 120, 2, 5.0, 24), (6, 120, 8, 3.0, 3), (3, 984, 5, 4.0, 1), (9, 8, 1, 2.0, 9)])
+def test_va_byword_step_equals_the_separate_launches(dev, R, K, nsym, snr, Bp):
+    """mvn_va_byword_step_f32: one launch = VADetector.forward('val') + RS decode + error count + RS encode + label word + trellis
+    states for R words (word r with row r % Bp of the state priors: its own channel), against mvn_va_decode_f32, mvn.rs_decode, a
+    plain comparison, mvn.rs_encode and calculate_states word by word; SNRs low enough that words exceed the code's capacity."""
+    T, L = K + 8 * nsym, 4
+    msg, rx = _words(dev, R, 1, K, nsym, [snr] * (R - 1) + [40.0], seed=3 * R + nsym)
+    msg, rx = msg[:, 0].contiguous(), rx[:, 0].contiguous()
+    va = mvn.VADetector(16, L, T, 1, "ISI_AWGN", 0, False, 1, {"train": "time_decay", "val": "time_decay"})
+    h = np.concatenate([mvn.estimate_channel(L, 0.2, "time_decay", fading=True, index=i, fading_taps_type=2) for i in range(Bp)])
+    if Bp > 1 and R >= 6:
+        h[1, 2] = np.nan  # one word's channel estimate is broken: torch.min's NaN rule inside the step's detector too
+    pri = va.compute_state_priors(h).to(dev).T.contiguous()  # [Bp, 16]
+    lib = mvn._lib.load()
+    out = dict(dec=torch.full((R, T), 7.0, device=dev), msg=torch.full((R, K), 7.0, device=dev), enc=torch.full((R, T), 7.0, device=dev),
+               lw=torch.full((R, T), 7.0, device=dev), labels=torch.full((R, T), -1, dtype=torch.int32, device=dev),
+               nerr=torch.full((R,), -1, dtype=torch.int32, device=dev))
+
+    def step(pilot, o):
+        rc = lib.mvn_va_byword_step_f32(mvn._lib.ptr(rx), T, mvn._lib.ptr(msg), K, mvn._lib.ptr(pri), Bp, mvn._lib.ptr(o["dec"]), T,
+                                        mvn._lib.ptr(o["msg"]), K, mvn._lib.ptr(o["enc"]), T, mvn._lib.ptr(o["lw"]), T,
+                                        mvn._lib.ptr(o["labels"]), T, mvn._lib.ptr(o["nerr"]), R, T, nsym, 1 if pilot else 0, 16,
+                                        mvn._lib.current_stream(dev))
+        assert rc == 0
+
+    step(False, out)
+    dec_ref = torch.empty((R, T), device=dev)
+    assert lib.mvn_va_decode_f32(mvn._lib.ptr(rx), T, mvn._lib.ptr(pri), Bp, mvn._lib.ptr(dec_ref), T, None, R, T, 16,
+                                 mvn._lib.current_stream(dev)) == 0
+    assert torch.equal(out["dec"], dec_ref)
+    dmsg = mvn.rs_decode(dec_ref, nsym)
+    enc = mvn.rs_encode(dmsg, nsym)
+    nerr = (dmsg != msg).sum(dim=1).to(torch.int32)
+    lw = torch.where((nerr > 0).reshape(-1, 1), dec_ref, enc)
+    assert torch.equal(out["msg"], dmsg) and torch.equal(out["enc"], enc) and torch.equal(out["nerr"], nerr)
+    assert torch.equal(out["lw"], lw) and torch.equal(out["labels"].long().reshape(-1), mvn.calculate_states(L, lw))
+    if R > 1:
+        assert int((nerr > 0).sum()) > 0  # the detected-word branch of the label rule ran
+    pil = {k: v.clone().fill_(7 if v.dtype.is_floating_point else -1) for k, v in out.items()}
+    step(True, pil)
+    enc_tx = mvn.rs_encode(msg, nsym)
+    assert torch.equal(pil["enc"], enc_tx) and torch.equal(pil["lw"], enc_tx) and int(pil["nerr"].abs().sum()) == 0
+    assert torch.equal(pil["labels"].long().reshape(-1), mvn.calculate_states(L, enc_tx))
+    assert bool((pil["dec"] == 7.0).all()) and bool((pil["msg"] == 7.0).all())
+
+
 def test_eval_by_word_fused_step_equals_separate_launches(golden, dev):
     """harness.eval_by_word with one launch per block against the four-launch route: the no-update loop of G7 (which is
     also pinned to the reference's ser_by_word there) and a self-supervised run (same draws): identical ser and weights."""
@@ -232,6 +278,59 @@ def test_batched_trials_equal_sequential_runs(golden, dev, monkeypatch, flow, fo
     if kw.get("self_supervised"):
         per_trial = rec["trained"].sum(axis=1)
         assert per_trial.min() < per_trial.max()  # different trials trained on different blocks
+
+
+SWITCH_FLOWS = {
+    # meta_weights_init('random') (trainer.py:356-359): fresh weights from the trial's own stream + a fresh optimizer per update
+    "random_init": dict(self_supervised=True, self_supervised_iterations=8, online_meta=True, meta_train_iterations=2, meta_j_num=4,
+                        meta_subframes=5, meta_style_online_training=True, weights_init="random"),
+    # buffer_empty=False (trainer.py:278-286, :325-328): the buffer starts with 6 words and stays 6 long
+    "window_buffer": dict(self_supervised=True, self_supervised_iterations=6, online_meta=True, meta_train_iterations=3, meta_j_num=4,
+                          meta_subframes=5, window_size=2, initial_buffer=6),
+    # the optimizers the kernels do not implement (trainer.py:163-175): trial after trial on stock autograd
+    "rmsprop": dict(self_supervised=True, self_supervised_iterations=3, online_meta=True, meta_train_iterations=1, meta_j_num=2,
+                    meta_subframes=5, optimizer_type="RMSprop"),
+    "sgd": dict(self_supervised=True, self_supervised_iterations=3, optimizer_type="SGD"),
+}
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("flow", sorted(SWITCH_FLOWS))
+def test_batched_evaluation_switches_equal_sequential_runs(golden, dev, flow):
+    """The reference's remaining eval_by_word switches inside trials.eval_by_word_batched -- weights_init='random',
+    buffer_empty=False, RMSprop / SGD -- per trial identical to harness.eval_by_word with the same draws: ser_by_word, weights,
+    optimizer state, step counts."""
+    kw = dict(SWITCH_FLOWS[flow])
+    opt = kw.pop("optimizer_type", "Adam")
+    R, N, K, nsym, sub = (3, 24, 120, 2, 25) if opt != "Adam" else (6, 46, 120, 2, 25)
+    T = K + 8 * nsym
+    snrs = [8.0 + r for r in range(R)]
+    w = _trial_weights(golden, R, seed=5)
+    msg, rx = _words(dev, R, N, K, nsym, snrs, seed=19)
+    ib = kw.pop("initial_buffer", None)
+    if ib:  # W0 words from the (training) channel: transmitted codewords and received words, shared by the trials
+        m0, r0 = _words(dev, 1, ib, K, nsym, [10.0], seed=77)
+        ib = (mvn.rs_encode(m0[0], nsym), r0[0])
+    bank = TrialBank(w, 16, 4, dev, optimizer_type=opt)
+    rec = {}
+    ser_b = eval_by_word_batched(bank, msg, rx, nsym, sub, [TrialDraws(300 + r, dev) for r in range(R)], record=rec,
+                                 initial_buffer=ib, **kw)
+    for r in range(R):
+        det = _vnet_with(w[r], T, dev)
+        tr = mvn.OnlineTrainer(det, 4, optimizer_type=opt)
+        ser = mvn.eval_by_word(det, msg[r], rx[r], snrs[r], 0.2, nsym, sub, online_trainer=tr,
+                               meta_detector=mvn.META_VNETDetector(16, {"train": T, "val": T}), draws=TrialDraws(300 + r, dev),
+                               initial_buffer=ib, **kw)
+        assert np.array_equal(ser, ser_b[r]), (flow, r)
+        for a, b in zip(det.parameters(), bank.weights(r)):
+            assert torch.equal(a.detach(), b), (flow, r)
+        assert torch.equal(tr.exp_avg, bank.exp_avg[r]) and torch.equal(tr.exp_avg_sq, bank.exp_avg_sq[r]), (flow, r)
+        assert tr.step == int(bank.step[r]), (flow, r)
+    assert int(rec["trained"].sum()) > R
+    if kw.get("online_meta"):
+        assert int(rec["meta"].sum()) >= R
+    if kw.get("weights_init") == "random":  # every update restarted the step count: far fewer steps than the blocks trained
+        assert int(bank.step.max()) <= 8 * 5 + 2 * 4
 
 
 @pytest.mark.timeout(900)

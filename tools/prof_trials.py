@@ -3,9 +3,13 @@ BASELINE flows with online training.  usage: prof_trials.py R "configs[2]"|"conf
 import os
 import sys
 
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from trial_setup import FLOWS, L, dev, nsym, sub, w, words  # noqa: E402
+from meta_viterbinet_amd.trials import TrialBank, TrialDraws, eval_by_word_batched  # noqa: E402
+
 R, flow = int(sys.argv[1]), sys.argv[2]
-sys.argv = [sys.argv[0]]
-exec(open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools/time_trials.py")).read().split("Rs = [int(a)")[0])
 name = [k for k in FLOWS if flow in k][0]
 coef, kw = FLOWS[name]
 ws = [words(coef, 7.0 + (i % 6), 100 + i) for i in range(R)]
