@@ -16,7 +16,7 @@ for e in re.split(r"\n\s+- \.agpr_count:", text)[1:]:
     vals.append((g("vgpr_count"), g("sgpr_count"), g("private_segment_fixed_size"), g("group_segment_fixed_size")))
 dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.strip().split("\n")
 for d, (v, s, p, l) in zip(dem, vals):
-    d = d.split("(anonymous namespace)::")[-1]
+    d = d.split("(anonymous namespace)::", 1)[-1]
     depth = 0
     for i, ch in enumerate(d):
         depth += ch == "<"
