@@ -549,9 +549,10 @@ __global__ __launch_bounds__(256) void isi_awgn_kernel(const float *__restrict__
 // They are read from the environment ONCE per process -- the by-word evaluation calls into the library every few
 // microseconds -- and again when the caller asks (mvn_reload_switches: the test-suite flips them between calls).
 enum Switch { SW_UNFUSED, SW_COOP, SW_FUSEDN, SW_GENERIC_SWEEP, SW_VA256, SW_VA_INPLACE, SW_VA16, SW_SWEEP_INPLACE, SW_SWEEP16,
-              SW_TRAIN_GROUPS, SW_COUNT };
+              SW_TRAIN_GROUPS, SW_TRAIN_PAIR, SW_COUNT };
 const char *const kSwitchNames[SW_COUNT] = {"MVN_UNFUSED", "MVN_COOP", "MVN_FUSEDN", "MVN_GENERIC_SWEEP", "MVN_VA256",
-                                            "MVN_VA_INPLACE", "MVN_VA16", "MVN_SWEEP_INPLACE", "MVN_SWEEP16", "MVN_TRAIN_GROUPS"};
+                                            "MVN_VA_INPLACE", "MVN_VA16", "MVN_SWEEP_INPLACE", "MVN_SWEEP16", "MVN_TRAIN_GROUPS",
+                                            "MVN_TRAIN_PAIR"};
 // The library may be called from several host threads: the table is atomics (a reload while another thread launches gives that
 // launch either the old or the new value of a switch, never a torn one), filled under a mutex.
 std::atomic<char> g_switch[SW_COUNT];
@@ -862,6 +863,23 @@ int plan_maml_groups(bool many, int R, int T, int W, int second_order, int S, bo
     return groups;
 }
 
+// More trials than CUs on one workgroup per trial: the 512-thread form of online_train_kernel puts TWO trials on a CU at once
+// (online_train.inc); it needs parameters + gradient + a compact arena within half a CU's LDS (n_states <= 16).  Measured
+// (tools/time_train_pair.py, profiles/r04_time_train_pair.txt): a 512-thread workgroup alone on a CU is 1.3-1.4 x slower than a
+// 1024-thread one, two of them together 1.09-1.10 x faster on whole-word iterations (512 / 1024 trials: 11.5 -> 10.5 ms,
+// 23.0 -> 20.8 ms per 200 iterations) and 0.92-0.94 x on 32-sample minibatch iterations, whose Adam update every 6.6 us waits for
+// its moments from global memory.  So: whole-word iterations with more trials than CUs only.  MVN_TRAIN_PAIR=0|1 pins the choice
+// (A/B, tests: the results are bit-identical either way).
+bool online_pair_form(bool many, int R, int M, int S) {
+    // 16 states only: the compact arena puts the column sums on the dlogits image, which is harmless only when EVERY column the
+    // products read of that image is rewritten by every chunk (for n_states < 16 columns n_states..15 are padding that must stay 0;
+    // 32 states do not fit half a CU's LDS)
+    if (!many || S != 16 || online_train2_lds_bytes(S) > (size_t)80 * 1024) return false;
+    const char e = sw(SW_TRAIN_PAIR);
+    if (e == '0' || e == '1') return e == '1';
+    return M == 0 && R > current_device_cus();
+}
+
 int launch_online_train(const mvn_train_trial_t &one, const mvn_train_trial_t *many, int R, int T, int M, float lr, float beta1,
                         float beta2, float eps, int S, void *workspace, size_t workspace_bytes, hipStream_t st) {
     const size_t lds = online_train_lds_bytes(S);
@@ -873,7 +891,12 @@ int launch_online_train(const mvn_train_trial_t &one, const mvn_train_trial_t *m
     if (!groups) {  // one workgroup per trial
         return dispatch_states(S, many != nullptr, [&](auto sc) -> int {
             constexpr int SC = decltype(sc)::value;
-            if (many) {
+            if (many && online_pair_form(true, R, M, S)) {
+                const size_t lds2 = online_train2_lds_bytes(S);
+                if (int e = ensure_dynamic_lds((const void *)online_train_kernel<SC == 32 ? 0 : SC, true, kTrainThreads2>, lds2)) return e;
+                hipLaunchKernelGGL((online_train_kernel<SC == 32 ? 0 : SC, true, kTrainThreads2>), dim3(1, (unsigned)R), dim3(kTrainThreads2),
+                                   lds2, st, one, many, T, M, lr, beta1, beta2, eps, S, (int)online_train2_lds_floats(S));
+            } else if (many) {
                 if (int e = ensure_dynamic_lds((const void *)online_train_kernel<SC == 32 ? 0 : SC, true>, lds)) return e;
                 hipLaunchKernelGGL((online_train_kernel<SC == 32 ? 0 : SC, true>), dim3(1, (unsigned)R), dim3(kTrainThreads), lds, st,
                                    one, many, T, M, lr, beta1, beta2, eps, S, lds_floats);
@@ -1261,7 +1284,9 @@ int mvn_vnet_train_kernel_name(int32_t kind, int32_t R, int32_t T, int32_t M_or_
                                  : plan_maml_groups(many, n_trials, T, M_or_W, kind == 2, S, workspace_bytes > 0, workspace_bytes);
     const int sc = S == 16 ? 16 : (S == 32 && !many) ? 32 : 0;  // dispatch_states
     const char *base = kind == 0 ? "online_train" : "maml_train";
-    if (!groups) {
+    if (!groups && kind == 0 && online_pair_form(many, n_trials, M_or_W, S)) {
+        snprintf(name, (size_t)name_len, "%s_kernel<%d, true, %d> 1x%d", base, sc, kTrainThreads2, n_trials);
+    } else if (!groups) {
         snprintf(name, (size_t)name_len, "%s_kernel<%d, %s> 1x%d", base, sc, many ? "true" : "false", n_trials);
     } else {
         const int per_launch = many ? trials_per_launch(n_trials, current_device_cus() / groups) : 1;

@@ -211,7 +211,10 @@ def _train_kernel_name(kind, R, T, M_or_W, S, ws_bytes):
 #   chunked   -- one workgroup per 32-sample chunk AND trial: *_train_groups_kernel<SC, true> (the launcher's choice for few trials)
 #   per_trial -- one workgroup per trial: online_train_kernel<SC, true> with M = 0, maml_train_kernel<SC, true> -- the launcher's
 #                choice from ~154 trials on, i.e. what bench.py times at 256 trials; forced here with MVN_TRAIN_GROUPS=0
-FORMS = {"chunked": "1", "per_trial": "0"}
+#   pair      -- one 512-thread workgroup per trial, two of them per CU (online_train_kernel<SC, true, 512>: the launcher's choice
+#                for more trials than CUs; Adam moments in global memory, every wave two roles per phase); MVN_TRAIN_PAIR=1
+FORMS = {"chunked": {"MVN_TRAIN_GROUPS": "1", "MVN_TRAIN_PAIR": "0"}, "per_trial": {"MVN_TRAIN_GROUPS": "0", "MVN_TRAIN_PAIR": "0"},
+         "pair": {"MVN_TRAIN_GROUPS": "0", "MVN_TRAIN_PAIR": "1"}}
 _SEQUENTIAL = {}
 
 
@@ -246,14 +249,19 @@ def test_batched_trials_equal_sequential_runs(golden, dev, monkeypatch, flow, fo
     snrs = [6.0, 7.0, 8.0, 9.0, 10.0, 11.0, 12.0]
     w = _trial_weights(golden, R, seed=3)
     msg, rx = _words(dev, R, N, K, nsym, snrs, seed=11)
-    monkeypatch.delenv("MVN_TRAIN_GROUPS", raising=False)
+    for name in ("MVN_TRAIN_GROUPS", "MVN_TRAIN_PAIR"):
+        monkeypatch.delenv(name, raising=False)
     seq = _sequential_runs(golden, dev, flow, R, N, K, nsym, sub, snrs, w, msg, rx, 100)
-    monkeypatch.setenv("MVN_TRAIN_GROUPS", FORMS[form])
+    for name, value in FORMS[form].items():
+        monkeypatch.setenv(name, value)
     W = kw.get("window_size", 1)
     ws_bytes = int(mvn._lib.load().mvn_vnet_train_trials_workspace_bytes(16, T, W, R))
     tag = "_groups_kernel<16, true>" if form == "chunked" else "_kernel<16, true> 1x"
-    if kw.get("meta_style_online_training"):  # full-word iterations (minibatch iterations are one chunk: one form only)
-        assert tag in _train_kernel_name(0, R, T, 0, 16, ws_bytes)
+    online_tag = "_kernel<16, true, 512> 1x" if form == "pair" else tag
+    if kw.get("meta_style_online_training"):  # full-word iterations
+        assert online_tag in _train_kernel_name(0, R, T, 0, 16, ws_bytes)
+    elif kw.get("self_supervised"):  # minibatch iterations are one chunk: one workgroup per trial, 1024 or 512 threads
+        assert ("_kernel<16, true, 512> 1x" if form == "pair" else "_kernel<16, true> 1x") in _train_kernel_name(0, R, T, 32, 16, ws_bytes)
     if kw.get("online_meta"):
         assert tag in _train_kernel_name(2 if kw.get("MAML", True) else 1, R, T, W, 16, ws_bytes)
     bank = TrialBank(w, 16, 4, dev)
@@ -468,7 +476,8 @@ def test_trial_entry_points_for_other_state_counts(dev, monkeypatch, S, T, form)
     single-trial entry points), minibatch and full-word iterations, second-order meta-learning steps."""
     from meta_viterbinet_amd import trials as tr_mod
 
-    monkeypatch.setenv("MVN_TRAIN_GROUPS", FORMS[form])
+    for name, value in FORMS[form].items():
+        monkeypatch.setenv(name, value)
     lib, L, R = mvn._lib.load(), int(np.log2(S)), 4
     rng = np.random.RandomState(S)
     gen = torch.Generator(device=dev).manual_seed(S)
@@ -514,7 +523,8 @@ def test_trial_entry_points_for_other_state_counts(dev, monkeypatch, S, T, form)
         wsb = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
         if mode != "minibatch":  # the run-time-S instantiations, in the form asked for
             named = _train_kernel_name(2 if mode == "maml" else 0, R, T, 1 if mode == "maml" else 0, S, nb)
-            assert ("_groups_kernel<0, true>" if form == "chunked" else "_kernel<0, true> 1x") in named, named  # (every T here is > 32)
+            # (the two-trials-per-CU form exists for 16 states only: asked for here, it must not be taken)
+            assert ("_groups_kernel<0, true>" if form == "chunked" else "_kernel<0, true> 1x") in named, named
         if mode == "maml":
             rc = lib.mvn_vnet_maml_train_trials_f32(mvn._lib.ptr(dd), R, T, 1, 0.1, 1, 1e-3, 0.9, 0.999, 1e-8, S, mvn._lib.ptr(wsb), nb,
                                                     mvn._lib.current_stream(dev))
