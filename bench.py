@@ -303,7 +303,29 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
         ws_b = int(lib.mvn_vnet_train_trials_workspace_bytes(16, T2, 1, trials))
         form = kernel_name(lib.mvn_vnet_train_kernel_name, 2 if maml else 0, trials, T2, 1 if maml else (0 if samples == T2 else samples), 16, ws_b)
         groups, per_launch = (int(v) for v in form.split("> ")[1].split(" ")[0].split("x"))
+        # the same flow priced by the MFMA instructions its training launches EXECUTE (SQ_INSTS_MFMA per iteration and trial from
+        # the committed PMC passes of tools/prof_train_kernels.py, profiles/train_pmc.json; x 2048 FLOP), and what those passes say
+        # the dominant training kernel waits for while it runs
+        executed, pmc_src, in_kernel = None, None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "train_pmc.json")))
+            if pmc.get("csrc_sha16") != csrc_sha16():
+                pmc_src = f"profiles/train_pmc.json: taken on another build of csrc/ ({pmc.get('csrc_sha16')}), not reported"
+            else:
+                c = pmc["cases"]
+                online_case = c["online_minibatch" if samples != T2 else ("online_full_word" if groups == 1 else "online_full_word_chunked")]
+                maml_case = c["maml_second_order" if groups == 1 else "maml_second_order_chunked"]
+                mfma = online_case["mfma_per_iteration"] * online_steps + maml_case["mfma_per_iteration"] * maml_steps
+                executed = mfma * 2048.0 / (stats["ms"] * 1e-3) / 1e12
+                dom = maml_case if maml else online_case
+                in_kernel = {k: dom[k] for k in ("kernel", "mfma_tflops_in_kernel", "mfma_busy", "lds_busy", "lds_bank_conflict_share_of_lds_cycles",
+                                                 "wait_barrier_or_waitcnt", "wait_issue", "issuing")}
+                pmc_src = f"profiles/train_pmc.json (rocprofv3 --pmc passes of tools/prof_train_kernels.py, csrc {pmc['csrc_sha16']})"
+        except (OSError, KeyError, ValueError) as e:
+            pmc_src = f"profiles/train_pmc.json: {type(e).__name__}"
         return {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "achieved_executed_mfma": executed, "frac_executed_mfma": None if executed is None else executed / PEAK_F32_MFMA_TFLOPS,
+                "dominant_kernel_while_running": in_kernel, "pmc_source": pmc_src,
                 "cu_occupancy": min(1.0, per_launch * groups / n_cu.value), "training_kernel": form, "workgroups_per_trial": groups,
                 "trials_per_launch": per_launch,
                 "adam_steps": stats["adam_steps"], "algorithmic_flop": flop}

@@ -119,14 +119,17 @@ int mvn_vnet_logits_f32(const float *y, const float *W1, const float *b1, const 
 
 /* Bytes of scratch mvn_vnet_decode_f32 wants to run (B,T,S) in one pass; any size that
  * holds at least one block (T*S*4 bytes) is accepted and processed in slices.  0 when the
- * shape is served by the fused kernel (S = 16), which needs none. */
+ * shape is served by a fused kernel (every S >= 4: the likelihood MLP runs inside the trellis
+ * sweep, the logits never reach HBM), which needs none; S = 2 and MVN_UNFUSED=1 take the
+ * two-kernel route (MLP -> logits in scratch -> sweep). */
 size_t mvn_vnet_workspace_bytes(int64_t B, int32_t T, int32_t S);
 
 /*
  * VNETDetector.forward(y,'val'), python_code/detectors/VNET/vnet_detector.py:35-61, and
  * META_VNETDetector.forward(y,'val',var), meta_vnet_detector.py:24-45 (var = the six arrays).
  *   y [B, y_ld>=T]; dec [B, dec_ld>=T]; logits_out [B,T,S] or NULL; final_metric [B,S] or NULL;
- *   workspace: device scratch (may be NULL when logits_out is given or the fused S=16 path runs).
+ *   workspace: device scratch (may be NULL when logits_out is given or a fused kernel runs: mvn_vnet_workspace_bytes == 0).
+ *   With logits_out the logits are materialised there (S != 16: by the two-kernel route).
  */
 int mvn_vnet_decode_f32(const float *y, int64_t y_ld, const float *W1, const float *b1,
                         const float *W2, const float *b2, const float *W3, const float *b3,

@@ -426,6 +426,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 #include "va_inplace.inc"
 #include "va256_wave.inc"
 #include "sweep_inplace.inc"
+#include "vnet_fused_ip.inc"
 #include "rs_codec.inc"
 #include "byword_step.inc"
 #include "online_train.inc"
@@ -1077,6 +1078,8 @@ int mvn_vnet_decode_kernel_name(int64_t B, int32_t T, int32_t S, int32_t want_lo
             snprintf(name, (size_t)name_len, "vnet16_coop_kernel<%s>", want_logits ? "true" : "false");
         else
             snprintf(name, (size_t)name_len, "vnet16_fusedn_kernel<%s, %d>", want_logits ? "true" : "false", fusedn_tiles());
+    } else if (!want_logits && !unfused_forced() && vnet_fused_ip_serves(S)) {  // one kernel: the MLP fused into the in-place sweep
+        snprintf(name, (size_t)name_len, "vnet_fused_ip_kernel<%d>", log2_states(S) - 2);
     } else {  // two launches: the MLP, then the sweep over its logits (scratch or logits_out: 16-byte aligned, row stride T)
         char sw[64];
         sweep_kernel_name<MODE_NEGLOGIT>(plan_sweep<MODE_NEGLOGIT>(nullptr, nullptr, 0, B, S), S, nullptr, 0, sw, sizeof sw);
@@ -1110,7 +1113,7 @@ int mvn_vnet_logits_f32(const float *y, const float *W1, const float *b1, const 
 
 size_t mvn_vnet_workspace_bytes(int64_t B, int32_t T, int32_t S) {
     if (B <= 0 || T <= 0 || S <= 0) return 0;
-    if (S == 16 && !unfused_forced()) return 0;  // the fused kernel keeps the logits on chip
+    if ((S == 16 || vnet_fused_ip_serves(S)) && !unfused_forced()) return 0;  // the fused kernels keep the logits on chip
     return (size_t)B * (size_t)T * (size_t)S * sizeof(float);
 }
 
@@ -1126,6 +1129,8 @@ int mvn_vnet_decode_f32(const float *y, int64_t y_ld, const float *W1, const flo
     if (S == 16 && !unfused_forced())  // fused single-kernel path: no scratch, 8 B/symbol of HBM traffic
         return launch_vnet16_fused(y, y_ld, W1, b1, W2, b2, W3, b3, dec, dec_ld, logits_out, final_metric, B, T, nullptr, 0,
                                    0, nullptr, nullptr, st);
+    if (!logits_out && !unfused_forced() && vnet_fused_ip_serves(S))  // every other S >= 4: the MLP fused into the in-place sweep
+        return launch_vnet_fused_ip(y, y_ld, W1, b1, W2, b2, W3, b3, dec, dec_ld, final_metric, B, T, S, st);
     const size_t per_block = (size_t)T * (size_t)S * sizeof(float);
     int64_t slice = B;
     float *buf = logits_out;

@@ -249,6 +249,40 @@ def test_vnet16_fused_and_unfused_paths(oracle, dev, monkeypatch, B, T):
                 assert np.array_equal(_np(lg), rlg)
 
 
+@pytest.mark.parametrize("S", [4, 8, 32, 64, 128, 256])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 7), (5, 17), (70, 136), (9, 1000), (260, 33)])
+def test_vnet_fused_ip_and_two_kernel_routes(oracle, dev, monkeypatch, S, B, T):
+    """Every S other than 16 (and 2): vnet_fused_ip_kernel<LB> -- the MLP fused into the in-place sweep, logits never in HBM --
+    by default, MVN_UNFUSED=1 the two-kernel route (mlp_kernel -> logits -> sweep_inplace_kernel).  Both give the oracle's
+    decisions and final path metrics bit for bit: blocks that do not fill a wave, T that is not a multiple of the chunk, a tile
+    that leaves the fast sigmoid's range, decision rows that are not 16-byte aligned (scalar stores) and a padded y stride."""
+    rng = np.random.RandomState(S + 3 * B + T)
+    w = _rand_weights(S, rng, scale=2.0)
+    y = rng.normal(0, 2, (B, T)).astype(np.float32)
+    y[B // 2, T // 2] = 75.0
+    wt = _weights_t(w, dev)
+    rdec, rfm = oracle.vnet_decode(y, w, want_final=True)
+    lib, st = mvn._lib.load(), mvn._lib.current_stream(dev)
+    name = ctypes.create_string_buffer(96)
+    for unfused in ("0", "1"):
+        monkeypatch.setenv("MVN_UNFUSED", unfused)
+        assert lib.mvn_vnet_decode_kernel_name(B, T, S, 0, name, 96) == 0
+        assert name.value.decode().startswith("vnet_fused_ip_kernel<" if unfused == "0" else "mlp_kernel<")
+        assert (int(lib.mvn_vnet_workspace_bytes(B, T, S)) == 0) == (unfused == "0")
+        for pad in (0, 3):  # row strides T and T + 3 (the latter: unaligned rows for most T)
+            yt = torch.zeros(B, T + pad, device=dev)
+            yt[:, :T] = torch.tensor(y, device=dev)
+            dec = torch.full((B, T + pad), 7.0, device=dev)
+            fm = torch.empty(B, S, device=dev)
+            ws = torch.empty(B * T * S * 4, dtype=torch.uint8, device=dev)
+            rc = lib.mvn_vnet_decode_f32(mvn._lib.ptr(yt), T + pad, *[mvn._lib.ptr(t) for t in wt], mvn._lib.ptr(dec), T + pad, None,
+                                         mvn._lib.ptr(fm), mvn._lib.ptr(ws), ws.numel(), B, T, S, st)
+            assert rc == 0
+            assert np.array_equal(_np(dec)[:, :T], rdec), (unfused, pad)
+            assert np.array_equal(_np(fm), rfm), (unfused, pad)
+            assert bool((dec[:, T:] == 7.0).all())  # columns beyond T are not touched
+
+
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 15), (4, 16), (5, 17), (2, 33), (7, 48), (9, 49), (67, 129), (130, 1000)])
 def test_sweep16_rows_and_generic_paths(oracle, dev, monkeypatch, B, T):
     """S=16 has a dedicated row-per-block DPP sweep; MVN_GENERIC_SWEEP=1 forces the generic LDS sweep.
@@ -1239,7 +1273,9 @@ def test_partial_nan_costs_are_dropped_by_the_sweeps(oracle, dev, monkeypatch, S
 VNET_NAN_ROUTES = [(16, {"MVN_COOP": "1"}), (16, {"MVN_COOP": "0"}), (16, {"MVN_COOP": "0", "MVN_FUSEDN": "4"}),
                    (16, {"MVN_UNFUSED": "1", "MVN_SWEEP16": "rows"}), (16, {"MVN_UNFUSED": "1", "MVN_SWEEP16": "lds"}),
                    (16, {"MVN_UNFUSED": "1", "MVN_SWEEP16": "quad"}), (16, {"MVN_UNFUSED": "1", "MVN_SWEEP_INPLACE": "1"}),
-                   (4, {}), (8, {}), (64, {}), (64, {"MVN_GENERIC_SWEEP": "1"}), (256, {}), (2, {})]
+                   (4, {}), (8, {}), (32, {}), (64, {}), (128, {}), (256, {}),  # vnet_fused_ip_kernel<LB>: the MLP fused into the sweep
+                   (4, {"MVN_UNFUSED": "1"}), (8, {"MVN_UNFUSED": "1"}), (64, {"MVN_UNFUSED": "1"}), (256, {"MVN_UNFUSED": "1"}),
+                   (64, {"MVN_UNFUSED": "1", "MVN_GENERIC_SWEEP": "1"}), (2, {})]
 
 
 @pytest.mark.parametrize("S,env", VNET_NAN_ROUTES, ids=[f"S{s}-" + "-".join(f"{k[4:]}{v}" for k, v in e.items()) for s, e in VNET_NAN_ROUTES])
