@@ -119,9 +119,10 @@ int mvn_vnet_logits_f32(const float *y, const float *W1, const float *b1, const 
 
 /* Bytes of scratch mvn_vnet_decode_f32 wants to run (B,T,S) in one pass; any size that
  * holds at least one block (T*S*4 bytes) is accepted and processed in slices.  0 when the
- * shape is served by a fused kernel (every S >= 4: the likelihood MLP runs inside the trellis
- * sweep, the logits never reach HBM), which needs none; S = 2 and MVN_UNFUSED=1 take the
- * two-kernel route (MLP -> logits in scratch -> sweep). */
+ * shape is served by a fused kernel (the likelihood MLP runs inside the trellis sweep, the
+ * logits never reach HBM), which needs none: S = 4 ... 64 by default, S = 128 and 256 with
+ * MVN_FUSED_IP=1 in the environment (there the two-kernel route -- MLP -> logits in scratch ->
+ * sweep -- is the faster one and the default; S = 2 and MVN_UNFUSED=1 always take it). */
 size_t mvn_vnet_workspace_bytes(int64_t B, int32_t T, int32_t S);
 
 /*

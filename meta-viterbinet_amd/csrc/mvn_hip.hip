@@ -550,10 +550,10 @@ __global__ __launch_bounds__(256) void isi_awgn_kernel(const float *__restrict__
 // They are read from the environment ONCE per process -- the by-word evaluation calls into the library every few
 // microseconds -- and again when the caller asks (mvn_reload_switches: the test-suite flips them between calls).
 enum Switch { SW_UNFUSED, SW_COOP, SW_FUSEDN, SW_GENERIC_SWEEP, SW_VA256, SW_VA_INPLACE, SW_VA16, SW_SWEEP_INPLACE, SW_SWEEP16,
-              SW_TRAIN_GROUPS, SW_TRAIN_PAIR, SW_COUNT };
+              SW_TRAIN_GROUPS, SW_TRAIN_PAIR, SW_FUSED_IP, SW_COUNT };
 const char *const kSwitchNames[SW_COUNT] = {"MVN_UNFUSED", "MVN_COOP", "MVN_FUSEDN", "MVN_GENERIC_SWEEP", "MVN_VA256",
                                             "MVN_VA_INPLACE", "MVN_VA16", "MVN_SWEEP_INPLACE", "MVN_SWEEP16", "MVN_TRAIN_GROUPS",
-                                            "MVN_TRAIN_PAIR"};
+                                            "MVN_TRAIN_PAIR", "MVN_FUSED_IP"};
 // The library may be called from several host threads: the table is atomics (a reload while another thread launches gives that
 // launch either the old or the new value of a switch, never a torn one), filled under a mutex.
 std::atomic<char> g_switch[SW_COUNT];
@@ -574,6 +574,17 @@ inline char sw(Switch i) {
 
 // MVN_UNFUSED=1 forces the two-kernel ViterbiNet path (MLP -> logits -> sweep) for testing.
 bool unfused_forced() { return sw(SW_UNFUSED) == '1'; }
+
+// ViterbiNet at S != 16: vnet_fused_ip_kernel<LB> (MLP inside the in-place sweep, no logits in HBM, no scratch) is the default
+// where it is also the faster route -- 4, 8, 32, 64 states: 1.05-1.11 x the two-kernel route at 10 000 blocks x 1000 -- and
+// opt-in (MVN_FUSED_IP=1) at 128 and 256 states, where a wave's chunk image and the W3 image leave one workgroup per CU and the
+// two-kernel route is 1.2-1.5 x faster (profiles/r04_time_vnet_states.txt).  MVN_FUSED_IP=0 / MVN_UNFUSED=1: never.
+bool fused_ip_selected(int S) {
+    if (unfused_forced() || S == 16 || S < 4 || S > 256 || (S & (S - 1))) return false;
+    const char e = sw(SW_FUSED_IP);
+    if (e == '0' || e == '1') return e == '1';
+    return S <= 64;
+}
 
 // Small batches take the cooperative kernel (vnet16_coop.inc); MVN_COOP=0|1 pins the choice (A/B runs, tests).
 bool coop_selected(int64_t B, int T) {
@@ -1078,7 +1089,7 @@ int mvn_vnet_decode_kernel_name(int64_t B, int32_t T, int32_t S, int32_t want_lo
             snprintf(name, (size_t)name_len, "vnet16_coop_kernel<%s>", want_logits ? "true" : "false");
         else
             snprintf(name, (size_t)name_len, "vnet16_fusedn_kernel<%s, %d>", want_logits ? "true" : "false", fusedn_tiles());
-    } else if (!want_logits && !unfused_forced() && vnet_fused_ip_serves(S)) {  // one kernel: the MLP fused into the in-place sweep
+    } else if (!want_logits && fused_ip_selected(S)) {  // one kernel: the MLP fused into the in-place sweep
         snprintf(name, (size_t)name_len, "vnet_fused_ip_kernel<%d>", log2_states(S) - 2);
     } else {  // two launches: the MLP, then the sweep over its logits (scratch or logits_out: 16-byte aligned, row stride T)
         char sw[64];
@@ -1113,7 +1124,7 @@ int mvn_vnet_logits_f32(const float *y, const float *W1, const float *b1, const 
 
 size_t mvn_vnet_workspace_bytes(int64_t B, int32_t T, int32_t S) {
     if (B <= 0 || T <= 0 || S <= 0) return 0;
-    if ((S == 16 || vnet_fused_ip_serves(S)) && !unfused_forced()) return 0;  // the fused kernels keep the logits on chip
+    if ((S == 16 && !unfused_forced()) || fused_ip_selected(S)) return 0;  // the fused kernels keep the logits on chip
     return (size_t)B * (size_t)T * (size_t)S * sizeof(float);
 }
 
@@ -1129,7 +1140,7 @@ int mvn_vnet_decode_f32(const float *y, int64_t y_ld, const float *W1, const flo
     if (S == 16 && !unfused_forced())  // fused single-kernel path: no scratch, 8 B/symbol of HBM traffic
         return launch_vnet16_fused(y, y_ld, W1, b1, W2, b2, W3, b3, dec, dec_ld, logits_out, final_metric, B, T, nullptr, 0,
                                    0, nullptr, nullptr, st);
-    if (!logits_out && !unfused_forced() && vnet_fused_ip_serves(S))  // every other S >= 4: the MLP fused into the in-place sweep
+    if (!logits_out && fused_ip_selected(S))  // other state counts: the MLP fused into the in-place sweep
         return launch_vnet_fused_ip(y, y_ld, W1, b1, W2, b2, W3, b3, dec, dec_ld, final_metric, B, T, S, st);
     const size_t per_block = (size_t)T * (size_t)S * sizeof(float);
     int64_t slice = B;

@@ -264,6 +264,7 @@ def test_vnet_fused_ip_and_two_kernel_routes(oracle, dev, monkeypatch, S, B, T):
     rdec, rfm = oracle.vnet_decode(y, w, want_final=True)
     lib, st = mvn._lib.load(), mvn._lib.current_stream(dev)
     name = ctypes.create_string_buffer(96)
+    monkeypatch.setenv("MVN_FUSED_IP", "1")  # (128 and 256 states take the fused kernel on request only: the two-kernel route is faster there)
     for unfused in ("0", "1"):
         monkeypatch.setenv("MVN_UNFUSED", unfused)
         assert lib.mvn_vnet_decode_kernel_name(B, T, S, 0, name, 96) == 0
@@ -1273,7 +1274,8 @@ def test_partial_nan_costs_are_dropped_by_the_sweeps(oracle, dev, monkeypatch, S
 VNET_NAN_ROUTES = [(16, {"MVN_COOP": "1"}), (16, {"MVN_COOP": "0"}), (16, {"MVN_COOP": "0", "MVN_FUSEDN": "4"}),
                    (16, {"MVN_UNFUSED": "1", "MVN_SWEEP16": "rows"}), (16, {"MVN_UNFUSED": "1", "MVN_SWEEP16": "lds"}),
                    (16, {"MVN_UNFUSED": "1", "MVN_SWEEP16": "quad"}), (16, {"MVN_UNFUSED": "1", "MVN_SWEEP_INPLACE": "1"}),
-                   (4, {}), (8, {}), (32, {}), (64, {}), (128, {}), (256, {}),  # vnet_fused_ip_kernel<LB>: the MLP fused into the sweep
+                   (4, {}), (8, {}), (32, {}), (64, {}), (128, {"MVN_FUSED_IP": "1"}), (256, {"MVN_FUSED_IP": "1"}),  # vnet_fused_ip_kernel<LB>
+                   (128, {}), (256, {}),
                    (4, {"MVN_UNFUSED": "1"}), (8, {"MVN_UNFUSED": "1"}), (64, {"MVN_UNFUSED": "1"}), (256, {"MVN_UNFUSED": "1"}),
                    (64, {"MVN_UNFUSED": "1", "MVN_GENERIC_SWEEP": "1"}), (2, {})]
 
