@@ -336,7 +336,9 @@ def test_sweep16_quad_variant(oracle, dev, monkeypatch):
     assert (lib.mvn_vnet_decode_kernel_name(10000, 1000, 16, 0, buf, 64), buf.value) == (0, b"vnet16_fusedn_kernel<false, 2>")
     assert (lib.mvn_vnet_decode_kernel_name(1, 136, 16, 0, buf, 64), buf.value) == (0, b"vnet16_coop_kernel<false>")
     assert (lib.mvn_vnet_decode_kernel_name(1, 2000, 16, 1, buf, 64), buf.value) == (0, b"vnet16_fusedn_kernel<true, 2>")  # T > 1024
-    assert (lib.mvn_vnet_decode_kernel_name(10, 100, 64, 0, buf, 64), buf.value) == (0, b"mlp_kernel<4> + sweep_inplace_kernel<4, 1, 4>")
+    assert (lib.mvn_vnet_decode_kernel_name(10, 100, 64, 0, buf, 64), buf.value) == (0, b"vnet_fused_ip_kernel<4>")  # MLP inside the sweep
+    assert (lib.mvn_vnet_decode_kernel_name(10, 100, 64, 1, buf, 64), buf.value) == (0, b"mlp_kernel<4> + sweep_inplace_kernel<4, 1, 4>")  # logits wanted
+    assert (lib.mvn_vnet_decode_kernel_name(10, 100, 256, 0, buf, 64), buf.value) == (0, b"mlp_kernel<16> + sweep_inplace_kernel<6, 1, 4>")  # fused on request only
     rng = np.random.RandomState(77)
     cost = rng.normal(0, 2, (B, T, S)).astype(np.float32)
     cost[:40] = np.round(cost[:40])  # exact ties
