@@ -64,6 +64,7 @@ class TrialDraws:
         self.rng = np.random.RandomState(self.seed % (2 ** 32))
         self._table = None
         self._shape = None
+        self._init_gen = None  # host generator of init_weights, created at its first use
 
     def batches(self, count: int, n_blocks: int, T: int, iterations: int, M: int) -> torch.Tensor:
         """int32 [iterations, M]: the minibatch indices of block `count` (a view into the trial's table)."""
@@ -82,7 +83,7 @@ class TrialDraws:
         nn.Linear's default reset_parameters (kaiming_uniform(a = sqrt 5) = U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and
         bias), layer by layer in parameters() order, from this trial's own stream (a host generator seeded by the trial's seed;
         successive calls continue the stream).  Six CPU tensors."""
-        if not hasattr(self, "_init_gen"):
+        if self._init_gen is None:
             self._init_gen = torch.Generator().manual_seed((self.seed * 2654435761 + 12345) % (2 ** 63))
         out = []
         for fan_out, fan_in in ((HIDDEN1_SIZE, 1), (HIDDEN2_SIZE, HIDDEN1_SIZE), (n_states, HIDDEN2_SIZE)):
