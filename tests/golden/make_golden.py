@@ -455,74 +455,113 @@ def g11_meta_train_loop():
     save("g11_meta_train_loop", **out)
 
 
-# ----------------------------------------------------------------------------- G12
+# ----------------------------------------------------------------------------- G12, G13
+def _by_word_flow(out, tag, cls, kw, g7, blocks_frames=3):
+    """One run of the unmodified reference's evaluate() -> eval_by_word (trainer.py:267-354, :368-381) from the reference-trained
+    weights of G7 (saved as the checkpoint load_weights reads), with every random draw it makes recorded in call order:
+    torch.multinomial (select_batch, :542), torch.randint (j_hat, :337) and -- weights_init='random' -- the weights
+    initialize_detector() produces (:356-359).  buffer_empty=False: the words eval_by_word draws from the training channel
+    (:282-286) are reproduced from a twin trainer with the same seeds (the two datasets share the trainer's RandomStates and
+    eval_by_word draws 'val' first, then 'train')."""
+    from python_code.ecc.rs_main import encode
+
+    torch.manual_seed(2024)
+    torch.set_num_threads(1)
+    wdir = os.path.join(TMP, "w_g12_" + tag)
+    os.makedirs(wdir, exist_ok=True)
+    base = dict(eval_mode="by_word", use_ecc=True, n_symbols=2, memory_length=4, val_block_length=120, val_frames=blocks_frames,
+                subframes_in_frame=25, channel_coefficients="time_decay", fading_in_channel=True, fading_in_decoder=False,
+                fading_taps_type=2, noisy_est_var=0, val_SNR_start=9, val_SNR_end=9, gamma=0.2, weights_dir=wdir, buffer_empty=True,
+                ser_thresh=0.02, noise_seed=3450002, word_seed=7860002)
+    base.update(kw)
+    tr = cls(**base)
+    sd = tr.detector.state_dict()
+    for i, k in enumerate(["net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias"]):
+        sd[k] = torch.tensor(g7[f"w{i}"])
+    torch.save({"model_state_dict": sd, "optimizer_state_dict": {}, "loss": 0.0}, os.path.join(wdir, "snr_9_gamma_0.2.pt"))
+    tx_msg, rx = tr.channel_dataset["val"].__getitem__(snr_list=[9], gamma=0.2)  # same seeds -> the words evaluate() will draw
+    if not base["buffer_empty"]:
+        btx, brx = tr.channel_dataset["train"].__getitem__(snr_list=[9], gamma=0.2)
+        out[f"{tag}_buffer_tx"] = np.stack([encode(w.int().numpy(), 2).reshape(-1) for w in btx]).astype(np.uint8)
+        out[f"{tag}_buffer_rx"] = brx.numpy().astype(np.float32)
+    tr2 = cls(**base)
+    multinomials, randints, inits = [], [], []
+    real_multinomial, real_randint, real_init = torch.multinomial, torch.randint, tr2.initialize_detector
+
+    def mspy(weights, n, *a, **k):
+        r = real_multinomial(weights, n, *a, **k)
+        multinomials.append(r.numpy().copy())
+        return r
+
+    def rspy(*a, **k):
+        r = real_randint(*a, **k)
+        randints.append((int(k["high"] if "high" in k else (a[1] if len(a) > 1 else a[0])), r.numpy().copy()))
+        return r
+
+    def ispy():
+        real_init()
+        inits.append(np.concatenate([w.reshape(-1) for w in export_weights(tr2.detector)]))
+
+    torch.multinomial, torch.randint, tr2.initialize_detector = mspy, rspy, ispy
+    try:
+        ser_by_word = tr2.evaluate()
+    finally:
+        torch.multinomial, torch.randint = real_multinomial, real_randint
+    out[f"{tag}_tx"] = tx_msg.numpy().astype(np.uint8)
+    out[f"{tag}_rx"] = rx.numpy().astype(np.float32)
+    out[f"{tag}_ser_by_word"] = np.asarray(ser_by_word, np.float64)
+    out[f"{tag}_multinomial"] = np.array(multinomials, np.int32).reshape(len(multinomials), -1 if multinomials else 0)
+    out[f"{tag}_randint_high"] = np.array([h for h, _ in randints], np.int64)
+    out[f"{tag}_randint"] = np.array([v for _, v in randints], np.int64).reshape(len(randints), -1 if randints else 0)
+    if inits:
+        out[f"{tag}_init_weights"] = np.stack(inits).astype(np.float32)
+    for i, w in enumerate(export_weights(tr2.detector)):
+        out[f"{tag}_w1_{i}"] = w
+    if base.get("online_meta"):
+        for i, w in enumerate(export_weights(tr2.saved_detector)):
+            out[f"{tag}_saved_{i}"] = w
+    out[f"{tag}_meta"] = np.array([kw["self_supervised_iterations"], kw.get("meta_train_iterations", 0), kw.get("meta_j_num", 0),
+                                   kw.get("meta_subframes", 0), 9, 25, 2], np.int64)
+    print("g12/13", tag, "blocks", len(ser_by_word), "mean ser", float(np.mean(ser_by_word)), "multinomial draws", len(multinomials),
+          "randint draws", len(randints), "re-initialisations", len(inits))
+
+
 def g12_by_word_with_updates():
-    """Trainer.eval_by_word WITH its update branches (trainer.py:267-354), run by the unmodified reference from the
-    reference-trained weights of G7: (a) VNETTrainer, self-supervised minibatch training after every qualifying block
-    (vnet_trainer.py:49-60); (b) METAVNETTrainer, online meta-learning every 5 blocks + whole-word training from the saved weights
-    (metavnet_trainer.py:52-64).  The reference draws from torch's global generator: torch.multinomial (select_batch,
-    trainer.py:542) and torch.randint (j_hat, :337) are wrapped to RECORD every draw, so that the flow can be replayed draw for
-    draw.  Stored: words, draws in call order, ser_by_word, final (and saved) weights."""
+    """Trainer.eval_by_word WITH its update branches: (a) VNETTrainer, self-supervised minibatch training after every qualifying
+    block (vnet_trainer.py:49-60); (b) METAVNETTrainer, online meta-learning every 5 blocks + whole-word training from the saved
+    weights (metavnet_trainer.py:52-64).  Stored: words, draws in call order, ser_by_word, final (and saved) weights."""
     from python_code.trainers.META_VNET.metavnet_trainer import METAVNETTrainer
 
     g7 = np.load(os.path.join(HERE, "g7_by_word.npz"))
     out = {}
-    flows = {"selfsup": (VNETTrainer, dict(self_supervised=True, self_supervised_iterations=12, online_meta=False)),
-             "meta": (METAVNETTrainer, dict(self_supervised=True, self_supervised_iterations=8, online_meta=True, MAML=True, meta_lr=0.1,
-                                            window_size=1, meta_train_iterations=2, meta_j_num=4, meta_subframes=5,
-                                            weights_init="last_frame"))}
-    for tag, (cls, kw) in flows.items():
-        torch.manual_seed(2024)
-        torch.set_num_threads(1)
-        wdir = os.path.join(TMP, "w_g12_" + tag)
-        os.makedirs(wdir, exist_ok=True)
-        tr = cls(eval_mode="by_word", use_ecc=True, n_symbols=2, memory_length=4, val_block_length=120, val_frames=3,
-                 subframes_in_frame=25, channel_coefficients="time_decay", fading_in_channel=True, fading_in_decoder=False,
-                 fading_taps_type=2, noisy_est_var=0, val_SNR_start=9, val_SNR_end=9, gamma=0.2, weights_dir=wdir, buffer_empty=True,
-                 ser_thresh=0.02, noise_seed=3450002, word_seed=7860002, **kw)
-        sd = tr.detector.state_dict()
-        for i, k in enumerate(["net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias"]):
-            sd[k] = torch.tensor(g7[f"w{i}"])
-        torch.save({"model_state_dict": sd, "optimizer_state_dict": {}, "loss": 0.0}, os.path.join(wdir, "snr_9_gamma_0.2.pt"))
-        tx_msg, rx = tr.channel_dataset["val"].__getitem__(snr_list=[9], gamma=0.2)  # same seeds -> the words evaluate() will draw
-        tr2 = cls(eval_mode="by_word", use_ecc=True, n_symbols=2, memory_length=4, val_block_length=120, val_frames=3,
-                  subframes_in_frame=25, channel_coefficients="time_decay", fading_in_channel=True, fading_in_decoder=False,
-                  fading_taps_type=2, noisy_est_var=0, val_SNR_start=9, val_SNR_end=9, gamma=0.2, weights_dir=wdir, buffer_empty=True,
-                  ser_thresh=0.02, noise_seed=3450002, word_seed=7860002, **kw)
-        multinomials, randints = [], []
-        real_multinomial, real_randint = torch.multinomial, torch.randint
-
-        def mspy(weights, n, *a, **k):
-            r = real_multinomial(weights, n, *a, **k)
-            multinomials.append(r.numpy().copy())
-            return r
-
-        def rspy(*a, **k):
-            r = real_randint(*a, **k)
-            randints.append((int(k["high"] if "high" in k else (a[1] if len(a) > 1 else a[0])), r.numpy().copy()))
-            return r
-
-        torch.multinomial, torch.randint = mspy, rspy
-        try:
-            ser_by_word = tr2.evaluate()
-        finally:
-            torch.multinomial, torch.randint = real_multinomial, real_randint
-        out[f"{tag}_tx"] = tx_msg.numpy().astype(np.uint8)
-        out[f"{tag}_rx"] = rx.numpy().astype(np.float32)
-        out[f"{tag}_ser_by_word"] = np.asarray(ser_by_word, np.float64)
-        out[f"{tag}_multinomial"] = np.array(multinomials, np.int32).reshape(len(multinomials), -1 if multinomials else 0)
-        out[f"{tag}_randint_high"] = np.array([h for h, _ in randints], np.int64)
-        out[f"{tag}_randint"] = np.array([v for _, v in randints], np.int64).reshape(len(randints), -1 if randints else 0)
-        for i, w in enumerate(export_weights(tr2.detector)):
-            out[f"{tag}_w1_{i}"] = w
-        if hasattr(tr2, "saved_detector") and tr2.saved_detector is not None:
-            for i, w in enumerate(export_weights(tr2.saved_detector)):
-                out[f"{tag}_saved_{i}"] = w
-        out[f"{tag}_meta"] = np.array([kw["self_supervised_iterations"], kw.get("meta_train_iterations", 0), kw.get("meta_j_num", 0),
-                                       kw.get("meta_subframes", 0), 9, 25, 2], np.int64)
-        print("g12", tag, "blocks", len(ser_by_word), "mean ser", float(np.mean(ser_by_word)), "multinomial draws", len(multinomials),
-              "randint draws", len(randints), "trained blocks ~", len(multinomials) // max(1, kw["self_supervised_iterations"]))
+    _by_word_flow(out, "selfsup", VNETTrainer, dict(self_supervised=True, self_supervised_iterations=12, online_meta=False), g7)
+    _by_word_flow(out, "meta", METAVNETTrainer, dict(self_supervised=True, self_supervised_iterations=8, online_meta=True, MAML=True,
+                                                     meta_lr=0.1, window_size=1, meta_train_iterations=2, meta_j_num=4,
+                                                     meta_subframes=5, weights_init="last_frame"), g7)
     save("g12_by_word_with_updates", **out)
+
+
+def g13_by_word_switches():
+    """The reference's remaining eval_by_word switches, one 50-block run each (same recording as G12): first-order meta-learning
+    (MAML=False, trainer.py:441-447), the pre-filled fixed-length buffer (buffer_empty=False, :278-286, :325-328), the three
+    meta_weights_init modes (:356-366: 'random' re-initialises the detector and the optimizer, 'meta_training' reloads the
+    checkpoint), a window of two support words, and the RMSprop / SGD optimizers (:163-175)."""
+    from python_code.trainers.META_VNET.metavnet_trainer import METAVNETTrainer
+
+    g7 = np.load(os.path.join(HERE, "g7_by_word.npz"))
+    out = {}
+    meta = dict(self_supervised=True, self_supervised_iterations=6, online_meta=True, MAML=True, meta_lr=0.1, window_size=1,
+                meta_train_iterations=2, meta_j_num=4, meta_subframes=5, weights_init="last_frame")
+    _by_word_flow(out, "fomaml", METAVNETTrainer, dict(meta, MAML=False), g7, 2)
+    _by_word_flow(out, "window", METAVNETTrainer, dict(meta, buffer_empty=False, train_block_length=120, train_frames=1), g7, 2)
+    _by_word_flow(out, "random", METAVNETTrainer, dict(meta, weights_init="random", meta_train_iterations=3), g7, 2)
+    _by_word_flow(out, "metatrain", METAVNETTrainer, dict(meta, weights_init="meta_training"), g7, 2)
+    _by_word_flow(out, "support2", METAVNETTrainer, dict(meta, window_size=2), g7, 2)
+    _by_word_flow(out, "rmsprop", VNETTrainer, dict(self_supervised=True, self_supervised_iterations=6, online_meta=False,
+                                                    optimizer_type="RMSprop"), g7, 2)
+    _by_word_flow(out, "sgd", VNETTrainer, dict(self_supervised=True, self_supervised_iterations=6, online_meta=False,
+                                                optimizer_type="SGD", lr=0.05), g7, 2)
+    save("g13_by_word_switches", **out)
 
 
 # ----------------------------------------------------------------------------- G8
@@ -577,13 +616,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g11":
         g11_meta_train_loop()
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "g12":
+    if len(sys.argv) > 1 and sys.argv[1] in ("g12", "g13"):
         import contextlib
         import io
 
         buf = io.StringIO()
-        with contextlib.redirect_stdout(buf):
-            g12_by_word_with_updates()
+        with contextlib.redirect_stdout(buf):  # (the reference prints every block)
+            g12_by_word_with_updates() if sys.argv[1] == "g12" else g13_by_word_switches()
         print("\n".join(l for l in buf.getvalue().splitlines() if l.startswith(("g12", "wrote"))))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g10":
@@ -614,5 +653,6 @@ if __name__ == "__main__":
         g11_meta_train_loop()
         g7_by_word(trained4)
         g12_by_word_with_updates()
+        g13_by_word_switches()
     print("\n".join(l for l in buf.getvalue().splitlines() if l.startswith(("time_decay", "cost2100", "wrote", "Final"))))
     print("torch", torch.__version__, "numpy", np.__version__)

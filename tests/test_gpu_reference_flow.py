@@ -1,4 +1,4 @@
-"""The reference's own `eval_by_word` WITH its update branches, replayed draw for draw (golden G12).
+"""The reference's own `eval_by_word` WITH its update branches, replayed draw for draw (goldens G12, G13).
 
 tests/golden/make_golden.py:g12_by_word_with_updates ran the unmodified reference (trainer.py:267-354) over 75 blocks from the
 reference-trained weights of G7, once as VNETTrainer (self-supervised minibatch training, vnet_trainer.py:49-60) and once as
@@ -7,7 +7,8 @@ recording every torch.multinomial / torch.randint draw it made.  Here the same w
 object that hands those recorded values back in call order, on the HIP kernels and on the torch-autograd path of the same host
 code.  What must come out: the reference's ser_by_word, block for block (the ser decides which blocks are buffered and trained
 on, so one differing block would also misalign the recorded draws — the draws object raises when that happens), every recorded
-draw consumed, and the final (and, in the meta flow, saved) weights within 5e-5 of the reference's."""
+draw consumed, and the final (and, in the meta flow, saved) weights within 5e-5 of the reference's.
+G13 (g13_by_word_switches) holds one such run per remaining switch of the reference's evaluation (FLOWS below)."""
 import numpy as np
 import pytest
 import torch
@@ -26,9 +27,10 @@ def dev():
 class RecordedDraws:
     """trials.TrialDraws' interface over the draws the reference made (in its call order)."""
 
-    def __init__(self, multinomial, randint_high, randint, device):
+    def __init__(self, multinomial, randint_high, randint, device, init_weights=None):
         self.multinomial, self.randint_high, self.randint, self.device = multinomial, randint_high, randint, device
-        self.m_at = self.r_at = 0
+        self.inits = np.zeros((0, 0), np.float32) if init_weights is None else init_weights
+        self.m_at = self.r_at = self.i_at = 0
 
     def batches(self, count, n_blocks, T, iterations, M):
         rows = self.multinomial[self.m_at:self.m_at + iterations]
@@ -52,34 +54,72 @@ class RecordedDraws:
             self.r_at += 1
         return np.concatenate(out)
 
+    def init_weights(self, n_states):
+        """the weights the reference's initialize_detector() produced at this re-initialisation (trainer.py:356-359)"""
+        if self.i_at >= len(self.inits):
+            raise AssertionError("a re-initialisation the reference did not make")
+        flat, out, at = torch.as_tensor(self.inits[self.i_at]), [], 0
+        self.i_at += 1
+        for shape in ((100, 1), (100,), (50, 100), (50,), (n_states, 50), (n_states,)):
+            n = int(np.prod(shape))
+            out.append(flat[at:at + n].reshape(shape))
+            at += n
+        assert at == flat.numel()
+        return out
+
     def used_up(self):
-        return self.m_at == len(self.multinomial) and self.r_at == len(self.randint)
+        return self.m_at == len(self.multinomial) and self.r_at == len(self.randint) and self.i_at == len(self.inits)
+
+
+# the harness arguments of every recorded flow beyond its iteration counts (tests/golden/make_golden.py: g12 / g13)
+FLOWS = {"selfsup": {}, "meta": dict(online_meta=True), "fomaml": dict(online_meta=True, MAML=False),
+         "window": dict(online_meta=True, window=True), "random": dict(online_meta=True, weights_init="random"),
+         "metatrain": dict(online_meta=True, weights_init="meta_training"), "support2": dict(online_meta=True, window_size=2),
+         "rmsprop": dict(optimizer_type="RMSprop"), "sgd": dict(optimizer_type="SGD", lr=0.05)}
+
+
+def _flow_kwargs(g, g7, tag, dev):
+    f = dict(FLOWS[tag])
+    ss_it, meta_it, j_num, meta_sub, _, subframes, nsym = [int(v) for v in g[f"{tag}_meta"]]
+    kw = dict(self_supervised=True, self_supervised_iterations=ss_it, ser_thresh=0.02)
+    if f.pop("online_meta", False):
+        kw.update(online_meta=True, meta_lr=0.1, MAML=f.pop("MAML", True), window_size=f.pop("window_size", 1),
+                  meta_train_iterations=meta_it, meta_j_num=j_num, meta_subframes=meta_sub, meta_style_online_training=True)
+        if "weights_init" in f:
+            kw["weights_init"] = f.pop("weights_init")
+            if kw["weights_init"] == "meta_training":  # the checkpoint the reference reloads = the weights the run started from
+                kw["meta_training_weights"] = [g7[f"w{i}"] for i in range(6)]
+        if f.pop("window", False):  # buffer_empty=False: the words the reference drew from its training channel
+            kw["initial_buffer"] = (torch.tensor(g[f"{tag}_buffer_tx"], device=dev).float(), torch.tensor(g[f"{tag}_buffer_rx"], device=dev))
+    return kw, f, nsym, subframes  # f: what is left is the optimizer's (optimizer_type, lr)
+
+
+def _recorded(g, tag, dev):
+    return RecordedDraws(g[f"{tag}_multinomial"], g[f"{tag}_randint_high"], g[f"{tag}_randint"], dev,
+                         g[f"{tag}_init_weights"] if f"{tag}_init_weights" in g.files else None)
 
 
 def _run(g, g7, tag, dev, hip):
     tx = torch.tensor(g[f"{tag}_tx"], device=dev).float()
     rx = torch.tensor(g[f"{tag}_rx"], device=dev)
-    ss_it, meta_it, j_num, meta_sub, _, subframes, nsym = [int(v) for v in g[f"{tag}_meta"]]
+    kw, opt, nsym, subframes = _flow_kwargs(g, g7, tag, dev)
     T = rx.shape[1]
     det = mvn.VNETDetector(16, {"train": T, "val": T}).to(dev)
     with torch.no_grad():
         for p, i in zip(det.parameters(), range(6)):
             p.copy_(torch.as_tensor(g7[f"w{i}"]))
-    tr = mvn.OnlineTrainer(det, 4, use_kernel=hip)
-    draws = RecordedDraws(g[f"{tag}_multinomial"], g[f"{tag}_randint_high"], g[f"{tag}_randint"], dev)
-    kw = dict(self_supervised=True, online_trainer=tr, self_supervised_iterations=ss_it, ser_thresh=0.02, draws=draws,
-              hip_meta=hip, graphed_meta=False)
-    if tag == "meta":
-        kw.update(online_meta=True, meta_detector=mvn.META_VNETDetector(16, {"train": T, "val": T}), meta_lr=0.1, MAML=True,
-                  window_size=1, meta_train_iterations=meta_it, meta_j_num=j_num, meta_subframes=meta_sub,
-                  meta_style_online_training=True)
+    tr = mvn.OnlineTrainer(det, 4, use_kernel=hip, **opt)
+    draws = _recorded(g, tag, dev)
+    if kw.get("online_meta"):
+        kw["meta_detector"] = mvn.META_VNETDetector(16, {"train": T, "val": T})
     last = {}
 
     def observer(seen):  # the saved weights (the reference's saved_detector, trainer.py:275/:343) as the last block leaves them
         if seen["stage"] == "end" and seen["saved_detector"] is not None:
             last["saved"] = [p.detach().cpu().numpy().copy() for p in seen["saved_detector"].parameters()]
 
-    ser = mvn.eval_by_word(det, tx, rx, 9.0, 0.2, nsym, subframes, observer=observer, **kw)
+    ser = mvn.eval_by_word(det, tx, rx, 9.0, 0.2, nsym, subframes, online_trainer=tr, draws=draws, hip_meta=hip, graphed_meta=False,
+                           observer=observer, **kw)
     return ser, draws, [p.detach().cpu().numpy() for p in det.parameters()], last.get("saved")
 
 
@@ -107,17 +147,44 @@ def test_reference_by_word_flow_with_updates(golden, dev, tag, hip):
     print(msg)
 
 
+G13 = ["fomaml", "window", "random", "metatrain", "support2", "rmsprop", "sgd"]
+
+
+@pytest.mark.parametrize("tag", G13)
+@pytest.mark.parametrize("hip", [True, False], ids=["hip_kernels", "torch_autograd"])
+def test_reference_by_word_switches(golden, dev, tag, hip):
+    """The reference's remaining eval_by_word switches, one recorded 50-block run each (golden G13): first-order meta-learning,
+    the pre-filled fixed-length buffer, meta_weights_init 'random' / 'meta_training', two support words, RMSprop, SGD (the last
+    two train on autograd in either parametrisation: the kernels implement Adam)."""
+    g, g7 = golden("g13_by_word_switches"), golden("g7_by_word")
+    ser, draws, w, saved = _run(g, g7, tag, dev, hip)
+    ref = g[f"{tag}_ser_by_word"]
+    assert ser.shape == ref.shape == (50,)
+    assert np.array_equal(ser, ref), (np.flatnonzero(ser != ref), ser[ser != ref], ref[ser != ref])
+    assert draws.used_up(), (draws.m_at, len(draws.multinomial), draws.r_at, len(draws.randint), draws.i_at, len(draws.inits))
+    moved = max(float(np.abs(g[f"{tag}_w1_{i}"] - g7[f"w{i}"]).max()) for i in range(6))
+    worst = max(float(np.abs(w[i] - g[f"{tag}_w1_{i}"]).max()) for i in range(6))
+    msg = f"g13 {tag} {'hip' if hip else 'torch'}: ser identical on 50 blocks; weights moved {moved:.4f}, end {worst:.2e} from the reference's"
+    assert moved > 0.01 and worst <= 5e-5, msg
+    if saved is not None:
+        worst_s = max(float(np.abs(saved[i] - g[f"{tag}_saved_{i}"]).max()) for i in range(6))
+        msg += f"; saved weights end {worst_s:.2e} from the reference's"
+        assert worst_s <= 5e-5, msg
+    print(msg)
+
+
 class RecordedTableDraws(RecordedDraws):
     """The same recorded draws for trials.eval_by_word_batched, which reads a trial's minibatches from a [blocks, iterations, M]
     table by block number: the reference's rows (call order) are laid at the blocks it trained on — the pilots and the data blocks
     whose ser it reported <= ser_thresh (trainer.py:345).  A run that trains on any other block reads rows of -1 and fails."""
 
     def __init__(self, g, tag, iterations, subframes, device):
-        super().__init__(g[f"{tag}_multinomial"], g[f"{tag}_randint_high"], g[f"{tag}_randint"], device)
+        super().__init__(g[f"{tag}_multinomial"], g[f"{tag}_randint_high"], g[f"{tag}_randint"], device,
+                         g[f"{tag}_init_weights"] if f"{tag}_init_weights" in g.files else None)
         ser = g[f"{tag}_ser_by_word"]
         trained = np.flatnonzero((np.arange(len(ser)) % subframes == 0) | (ser <= 0.02))
         table = np.full((len(ser), iterations, 32), -1, np.int32)
-        if len(self.multinomial):
+        if self.multinomial.size:
             assert len(self.multinomial) == iterations * len(trained)
             table[trained] = self.multinomial.reshape(len(trained), iterations, 32)
         self._table = torch.as_tensor(table, device=device)
@@ -128,23 +195,21 @@ class RecordedTableDraws(RecordedDraws):
         return self._table[count]
 
 
-@pytest.mark.parametrize("tag", ["selfsup", "meta"])
+@pytest.mark.parametrize("tag", ["selfsup", "meta"] + G13)
 def test_reference_by_word_flow_batched_trials(golden, dev, tag):
-    """The same two reference runs as R = 3 identical trials of eval_by_word_batched (the trial-batched training kernels): every
-    row must reproduce the reference's ser_by_word and end on its weights."""
+    """The same reference runs as R = 3 identical trials of eval_by_word_batched (the trial-batched training kernels; RMSprop / SGD:
+    its trial-after-trial autograd route): every row must reproduce the reference's ser_by_word and end on its weights."""
     from meta_viterbinet_amd.trials import TrialBank, eval_by_word_batched
 
-    g, g7 = golden("g12_by_word_with_updates"), golden("g7_by_word")
+    g, g7 = golden("g12_by_word_with_updates" if tag in ("selfsup", "meta") else "g13_by_word_switches"), golden("g7_by_word")
     R = 3
-    ss_it, meta_it, j_num, meta_sub, _, subframes, nsym = [int(v) for v in g[f"{tag}_meta"]]
+    kw, opt, nsym, subframes = _flow_kwargs(g, g7, tag, dev)
     tx = torch.tensor(g[f"{tag}_tx"], device=dev).float().unsqueeze(0).repeat(R, 1, 1)
     rx = torch.tensor(g[f"{tag}_rx"], device=dev).unsqueeze(0).repeat(R, 1, 1)
-    bank = TrialBank([[g7[f"w{i}"] for i in range(6)]] * R, 16, 4, dev)
-    draws = [RecordedTableDraws(g, tag, ss_it, subframes, dev) for _ in range(R)]
-    kw = dict(self_supervised=True, self_supervised_iterations=ss_it, ser_thresh=0.02)
-    if tag == "meta":
-        kw.update(online_meta=True, meta_lr=0.1, MAML=True, window_size=1, meta_train_iterations=meta_it, meta_j_num=j_num,
-                  meta_subframes=meta_sub, meta_style_online_training=True)
+    bank = TrialBank([[g7[f"w{i}"] for i in range(6)]] * R, 16, 4, dev, **opt)
+    draws = [RecordedTableDraws(g, tag, kw["self_supervised_iterations"], subframes, dev) for _ in range(R)]
+    if opt:  # trial after trial through harness.eval_by_word: the draws are asked for in call order
+        draws = [_recorded(g, tag, dev) for _ in range(R)]
     ser = eval_by_word_batched(bank, tx, rx, nsym, subframes, draws, **kw)
     ref = g[f"{tag}_ser_by_word"]
     for r in range(R):
@@ -152,7 +217,7 @@ def test_reference_by_word_flow_batched_trials(golden, dev, tag):
         assert draws[r].used_up()
         worst = max(float(np.abs(w.cpu().numpy() - g[f"{tag}_w1_{i}"]).max()) for i, w in enumerate(bank.weights(r)))
         assert worst <= 5e-5, (r, worst)
-        if tag == "meta":
-            worst_s = max(float(np.abs(w.cpu().numpy() - g[f"meta_saved_{i}"]).max()) for i, w in enumerate(bank.weights(r, saved=True)))
+        if kw.get("online_meta"):
+            worst_s = max(float(np.abs(w.cpu().numpy() - g[f"{tag}_saved_{i}"]).max()) for i, w in enumerate(bank.weights(r, saved=True)))
             assert worst_s <= 5e-5, (r, worst_s)
     assert torch.equal(bank.theta[0], bank.theta[1]) and torch.equal(bank.theta[0], bank.theta[2])
