@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r04p
 mkdir -p $O
 # whatever happens, the raw rocprofv3 directories do not travel home (gpurun_out/ is merged back only below 64 MiB)
-trap 'rm -rf $O/kt $O/kh $O/pmc/FETCH_SIZE $O/pmc/WRITE_SIZE $O/pmc/TCC* $O/pmc/SQ* $O/pmc_train/pass*/ $O/pmc_head*/pass*/' EXIT
+trap 'rm -rf $O/kt $O/kh $O/pmc/FETCH_SIZE $O/pmc/WRITE_SIZE $O/pmc/TCC* $O/pmc/SQ* $O/pmc_train/pass*/ $O/pmc_head*/pass*/ $O/pmc_va256/pass*/' EXIT
 # the counter passes first: bench.py reads profiles/traffic.json, valu_insts.json and train_pmc.json and ignores them unless they
 # carry the sha of the kernel sources it runs (they are copied into profiles/ here, on the box; copy them again from gpurun_out/ at home)
 cd $R && bash tools/pmc_traffic.sh gpurun_out/r04p/pmc > $O/pmc.log 2>&1
@@ -20,7 +20,9 @@ for B in 10000 40960; do
   bash tools/pmc_sq.sh gpurun_out/r04p/pmc_head$B tools/prof_headline.py $B 5 > $O/pmc_head$B.log 2>&1
   python3 tools/pmc_dispatch_table.py gpurun_out/r04p/pmc_head$B fusedn | (read h; echo "$h"; tail -5) > $O/headline_pmc_$B.csv
 done
-echo pmc headline done
+bash tools/pmc_sq.sh gpurun_out/r04p/pmc_va256 tools/prof_va256.py 125000 3 > $O/pmc_va256.log 2>&1
+python3 tools/pmc_dispatch_table.py gpurun_out/r04p/pmc_va256 va256_wave | (read h; echo "$h"; tail -3) > $O/va256_pmc.csv
+echo pmc headline + va256 done
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 echo bench done
@@ -38,5 +40,5 @@ python3 tools/time_trials.py 1 6 16 51 102 204 256 512 2>&1 | grep -v amdgpu.ids
 python3 tools/time_step.py 2>&1 | grep -v amdgpu.ids > $O/time_step.txt
 python3 tools/time_online.py 2>&1 | grep -v amdgpu.ids > $O/time_online_training.txt
 timeout -k 10 200 python3 tools/fuzz_parity.py 120 2>&1 | grep -v amdgpu.ids | tail -5 > $O/fuzz_parity.txt
-rm -rf $O/kt $O/kh $O/pmc/FETCH_SIZE $O/pmc/WRITE_SIZE $O/pmc/TCC* $O/pmc/SQ* $O/pmc_train/pass*/ $O/pmc_head*/pass*/
+rm -rf $O/kt $O/kh $O/pmc/FETCH_SIZE $O/pmc/WRITE_SIZE $O/pmc/TCC* $O/pmc/SQ* $O/pmc_train/pass*/ $O/pmc_head*/pass*/ $O/pmc_va256/pass*/
 ls $O $O/pmc
