@@ -564,6 +564,50 @@ def g13_by_word_switches():
     save("g13_by_word_switches", **out)
 
 
+# ----------------------------------------------------------------------------- G14
+def g14_aggregated_evaluate():
+    """Trainer.evaluate() in 'aggregated' mode (trainer.py:368-381 -> evaluate_at_point :254-265 -> gamma_eval :243-252 ->
+    single_eval_at_point :222-241) over three SNR points, run by the unmodified reference as VATrainer, VNETTrainer and
+    METAVNETTrainer, coded (use_ecc=True: RS(17,15) decoding of every detected word before the error rates) and uncoded.
+    Stored: the words of every SNR point (a twin trainer with the same seeds draws them in the same order), the weights the
+    run loaded (G7's, saved as the checkpoint of every SNR point), the data rows and the ser vector evaluate() returned."""
+    from python_code.trainers.META_VNET.metavnet_trainer import METAVNETTrainer
+
+    g7 = np.load(os.path.join(HERE, "g7_by_word.npz"))
+    out, names = {}, []
+    torch.set_num_threads(1)
+    for tag, cls, ecc in (("va_coded", VATrainer, True), ("va_plain", VATrainer, False), ("vnet_coded", VNETTrainer, True),
+                          ("vnet_plain", VNETTrainer, False), ("meta_coded", METAVNETTrainer, True)):
+        wdir = os.path.join(TMP, "w_g14_" + tag)
+        os.makedirs(wdir, exist_ok=True)
+        kw = dict(eval_mode="aggregated", use_ecc=ecc, n_symbols=2, memory_length=4, val_block_length=120, val_frames=2,
+                  subframes_in_frame=25, channel_coefficients="time_decay", fading_in_channel=True, fading_in_decoder=cls is VATrainer,
+                  fading_taps_type=2, noisy_est_var=0, val_SNR_start=8, val_SNR_end=10, val_SNR_step=1, gamma=0.2, weights_dir=wdir,
+                  self_supervised=False, online_meta=False, noise_seed=3450002, word_seed=7860002)
+        twin, tr = cls(**kw), cls(**kw)
+        if cls is not VATrainer:
+            sd = tr.detector.state_dict()
+            for i, k in enumerate(["net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias"]):
+                sd[k] = torch.tensor(g7[f"w{i}"])
+            for snr in (8, 9, 10):
+                torch.save({"model_state_dict": sd, "optimizer_state_dict": {}, "loss": 0.0}, os.path.join(wdir, f"snr_{snr}_gamma_0.2.pt"))
+        for snr in (8, 9, 10):  # gamma_eval's order
+            tx, rx = twin.channel_dataset["val"].__getitem__(snr_list=[snr], gamma=0.2)
+            if tag == "meta_coded":  # same seeds, same class of dataset: the words of vnet_coded (not stored twice)
+                assert np.array_equal(out[f"vnet_coded_rx{snr}"], rx.numpy()) and np.array_equal(out[f"vnet_coded_tx{snr}"], tx.numpy())
+                continue
+            out[f"{tag}_tx{snr}"] = tx.numpy().astype(np.uint8)
+            out[f"{tag}_rx{snr}"] = rx.numpy().astype(np.float32)
+        ser = tr.evaluate()
+        out[f"{tag}_ser"] = np.asarray(ser, np.float64)
+        out[f"{tag}_data_indices"] = tr.data_indices.numpy()
+        out[f"{tag}_meta"] = np.array([int(ecc), 2, 4, 50, 136 if ecc else 120], np.int64)
+        names.append(tag)
+        print("g14", tag, "ser", ser)
+    out["names"] = np.array(names)
+    save("g14_aggregated_evaluate", **out)
+
+
 # ----------------------------------------------------------------------------- G8
 def g8_rs():
     """RS(n,k) KATs through the reference's own encode/decode (rs_main.py:9-37), incl. patterns beyond the
@@ -616,6 +660,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g11":
         g11_meta_train_loop()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g14":
+        g14_aggregated_evaluate()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] in ("g12", "g13"):
         import contextlib
         import io
@@ -654,5 +701,6 @@ if __name__ == "__main__":
         g7_by_word(trained4)
         g12_by_word_with_updates()
         g13_by_word_switches()
+        g14_aggregated_evaluate()
     print("\n".join(l for l in buf.getvalue().splitlines() if l.startswith(("time_decay", "cost2100", "wrote", "Final"))))
     print("torch", torch.__version__, "numpy", np.__version__)

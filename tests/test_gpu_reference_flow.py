@@ -221,3 +221,34 @@ def test_reference_by_word_flow_batched_trials(golden, dev, tag):
             worst_s = max(float(np.abs(w.cpu().numpy() - g[f"{tag}_saved_{i}"]).max()) for i, w in enumerate(bank.weights(r, saved=True)))
             assert worst_s <= 5e-5, (r, worst_s)
     assert torch.equal(bank.theta[0], bank.theta[1]) and torch.equal(bank.theta[0], bank.theta[2])
+
+
+@pytest.mark.parametrize("tag", ["va_coded", "va_plain", "vnet_coded", "vnet_plain", "meta_coded"])
+def test_reference_aggregated_evaluate(golden, dev, tag):
+    """Golden G14: the reference's evaluate() in 'aggregated' mode (trainer.py:368-381 -> :254-265 -> :243-252 -> :222-241) over
+    three SNR points as VATrainer / VNETTrainer / METAVNETTrainer, coded and uncoded.  harness.single_eval_at_point on the words the
+    reference drew must return its ser at every point (the reference takes a float32 mean of the bit errors, the harness divides
+    integer counters: equal to the last bits of a float32), and the generated-words route must reproduce those words."""
+    g, g7 = golden("g14_aggregated_evaluate"), golden("g7_by_word")
+    ecc, nsym, L, words, T = [int(v) for v in g[f"{tag}_meta"]]
+    src = "vnet_coded" if tag == "meta_coded" else tag
+    if tag.startswith("va"):
+        det = mvn.VADetector(16, L, T, words, "ISI_AWGN", 0, True, 2, {"train": "time_decay", "val": "time_decay"})
+    else:
+        det = (mvn.META_VNETDetector if tag.startswith("meta") else mvn.VNETDetector)(16, {"train": T, "val": T}).to(dev)
+        w = [torch.tensor(g7[f"w{i}"], device=dev) for i in range(6)]
+        if tag.startswith("meta"):  # the reference's trainer calls its plain detector either way (metavnet_trainer.py:30-39)
+            meta, det = det, (lambda rx, phase, snr, gamma: meta(rx, phase, w))
+        else:
+            with torch.no_grad():
+                for p, a in zip(det.parameters(), w):
+                    p.copy_(a)
+    rows = torch.tensor(g[f"{tag}_data_indices"], device=dev)
+    for k, snr in enumerate((8, 9, 10)):
+        tx = torch.tensor(g[f"{src}_tx{snr}"], device=dev).float()
+        rx = torch.tensor(g[f"{src}_rx{snr}"], device=dev)
+        ser, fer, c = mvn.single_eval_at_point(det, tx, rx, float(snr), 0.2, rows, n_symbols=nsym if ecc else 0)
+        ref = float(g[f"{tag}_ser"][k])
+        assert c.tolist()[1] == len(rows) * 120 and c.tolist()[3] == len(rows)
+        assert ser == pytest.approx(ref, rel=2e-6, abs=1e-9), (tag, snr, ser, ref)
+        assert int(c[0]) == int(round(ref * len(rows) * 120)), (tag, snr)  # the integer behind the reference's mean
