@@ -228,7 +228,7 @@ def test_reference_aggregated_evaluate(golden, dev, tag):
     """Golden G14: the reference's evaluate() in 'aggregated' mode (trainer.py:368-381 -> :254-265 -> :243-252 -> :222-241) over
     three SNR points as VATrainer / VNETTrainer / METAVNETTrainer, coded and uncoded.  harness.single_eval_at_point on the words the
     reference drew must return its ser at every point (the reference takes a float32 mean of the bit errors, the harness divides
-    integer counters: equal to the last bits of a float32), and the generated-words route must reproduce those words."""
+    integer counters: the same number of bit errors, the ratio equal to float32 rounding), and the generated-words route must reproduce those words."""
     g, g7 = golden("g14_aggregated_evaluate"), golden("g7_by_word")
     ecc, nsym, L, words, T = [int(v) for v in g[f"{tag}_meta"]]
     src = "vnet_coded" if tag == "meta_coded" else tag
@@ -250,5 +250,5 @@ def test_reference_aggregated_evaluate(golden, dev, tag):
         ser, fer, c = mvn.single_eval_at_point(det, tx, rx, float(snr), 0.2, rows, n_symbols=nsym if ecc else 0)
         ref = float(g[f"{tag}_ser"][k])
         assert c.tolist()[1] == len(rows) * 120 and c.tolist()[3] == len(rows)
-        assert ser == pytest.approx(ref, rel=2e-6, abs=1e-9), (tag, snr, ser, ref)
+        assert ser == pytest.approx(ref, rel=2e-5, abs=1e-7), (tag, snr, ser, ref)  # (the reference's mean carries float32 rounding)
         assert int(c[0]) == int(round(ref * len(rows) * 120)), (tag, snr)  # the integer behind the reference's mean
