@@ -550,10 +550,10 @@ __global__ __launch_bounds__(256) void isi_awgn_kernel(const float *__restrict__
 // They are read from the environment ONCE per process -- the by-word evaluation calls into the library every few
 // microseconds -- and again when the caller asks (mvn_reload_switches: the test-suite flips them between calls).
 enum Switch { SW_UNFUSED, SW_COOP, SW_FUSEDN, SW_GENERIC_SWEEP, SW_VA256, SW_VA_INPLACE, SW_VA16, SW_SWEEP_INPLACE, SW_SWEEP16,
-              SW_TRAIN_GROUPS, SW_TRAIN_PAIR, SW_FUSED_IP, SW_COUNT };
+              SW_TRAIN_GROUPS, SW_TRAIN_PAIR, SW_FUSED_IP, SW_TRAIN_XCD, SW_COUNT };
 const char *const kSwitchNames[SW_COUNT] = {"MVN_UNFUSED", "MVN_COOP", "MVN_FUSEDN", "MVN_GENERIC_SWEEP", "MVN_VA256",
                                             "MVN_VA_INPLACE", "MVN_VA16", "MVN_SWEEP_INPLACE", "MVN_SWEEP16", "MVN_TRAIN_GROUPS",
-                                            "MVN_TRAIN_PAIR", "MVN_FUSED_IP"};
+                                            "MVN_TRAIN_PAIR", "MVN_FUSED_IP", "MVN_TRAIN_XCD"};
 // The library may be called from several host threads: the table is atomics (a reload while another thread launches gives that
 // launch either the old or the new value of a switch, never a torn one), filled under a mutex.
 std::atomic<char> g_switch[SW_COUNT];
@@ -819,6 +819,19 @@ size_t trial_workspace_floats(int S, int groups) {
     return ((maml_groups_workspace_bytes(S, groups) + 255) & ~(size_t)255) / sizeof(float);
 }
 
+// The chunked training launches place a trial's workgroups on ONE XCD (train_groups.inc, group_place): a 1-D grid in units of
+// 8 x groups blocks, 8 trials per unit; the trial's gradient exchange then stays in that XCD's L2 (a whole-word iteration of one
+// trial 9.4 -> 8.8 us, a second-order step 38 -> 36 us; profiles/r04_time_groups_xcd_ab.txt).  The units hold a few trials less
+// per launch than CUs / groups (48 instead of 51 at 5 workgroups per trial): the (groups, trials) grid, whose workgroups of a
+// trial land on different XCDs, stays where the XCD-aware one would need more launches.  MVN_TRAIN_XCD=0: never (A/B; same bits).
+bool xcd_grid(int groups, int cus, int R) {
+    if (sw(SW_TRAIN_XCD) == '0' || groups < 2 || 8 * groups > cus) return false;
+    const int fit_x = 8 * (cus / (8 * groups)), fit_c = cus / groups;
+    return (R + fit_x - 1) / fit_x <= (R + fit_c - 1) / fit_c;
+}
+int group_trials_fit(int groups, int cus, int R) { return xcd_grid(groups, cus, R) ? 8 * (cus / (8 * groups)) : cus / groups; }
+unsigned group_grid_blocks(int groups, int trials) { return (unsigned)(8 * groups * ((trials + 7) / 8)); }
+
 // R trials, at most `fit` per launch (workgroups <= CUs): as few launches as possible, of equal size (29 trials with room for
 // 28 run as 15 + 14, not 28 + 1)
 int trials_per_launch(int R, int fit) {
@@ -835,7 +848,7 @@ int trials_per_launch(int R, int fit) {
 // forms give the same bits.)
 bool one_workgroup_per_trial_is_faster(int R, int groups, int cus, double slowdown) {
     if (groups < 2 || cus < groups) return true;
-    const int fit = cus / groups;
+    const int fit = group_trials_fit(groups, cus, R);
     const double chunked = (double)((R + fit - 1) / fit), single = slowdown * (double)((R + cus - 1) / cus);
     return single < chunked;
 }
@@ -922,22 +935,25 @@ int launch_online_train(const mvn_train_trial_t &one, const mvn_train_trial_t *m
     }
     // one workgroup per chunk and trial, never more workgroups in a launch than the device has CUs (all resident at once)
     const size_t ws_floats_one = train_groups_workspace_bytes(S, groups) / sizeof(float);
-    const int per_launch = many ? trials_per_launch(R, cus / groups) : 1;
+    const bool xcd = xcd_grid(groups, cus, R);
+    const int per_launch = many ? trials_per_launch(R, group_trials_fit(groups, cus, R)) : 1;
     for (int r0 = 0; r0 < R; r0 += per_launch) {
         const int nr = std::min(per_launch, R - r0);
         float *wsr = (float *)workspace + (size_t)r0 * stride;
         hipError_t e = clear_group_syncs(wsr, stride, nr, st);
         if (e != hipSuccess) return (int)e;
-        const GroupLaunch gl = {wsr, (long long)stride, (unsigned)((many ? stride : ws_floats_one) * sizeof(float)), group_spin_limit(), group_phantoms()};
+        const GroupLaunch gl = {wsr, (long long)stride, (unsigned)((many ? stride : ws_floats_one) * sizeof(float)), group_spin_limit(), group_phantoms(),
+                                xcd ? groups : 0, nr};
+        const dim3 grid = xcd ? dim3(group_grid_blocks(groups, nr)) : dim3((unsigned)groups, (unsigned)nr);
         const int rc = dispatch_states(S, many != nullptr, [&](auto sc) -> int {
             constexpr int SC = decltype(sc)::value;
             if (many) {
                 if (int e2 = ensure_dynamic_lds((const void *)online_train_groups_kernel<SC == 32 ? 0 : SC, true>, lds)) return e2;
-                hipLaunchKernelGGL((online_train_groups_kernel<SC == 32 ? 0 : SC, true>), dim3((unsigned)groups, (unsigned)nr),
+                hipLaunchKernelGGL((online_train_groups_kernel<SC == 32 ? 0 : SC, true>), grid,
                                    dim3(kTrainThreads), lds, st, one, many + r0, T, lr, beta1, beta2, eps, S, lds_floats, gl);
             } else {
                 if (int e2 = ensure_dynamic_lds((const void *)online_train_groups_kernel<SC, false>, lds)) return e2;
-                hipLaunchKernelGGL((online_train_groups_kernel<SC, false>), dim3((unsigned)groups), dim3(kTrainThreads), lds, st, one,
+                hipLaunchKernelGGL((online_train_groups_kernel<SC, false>), grid, dim3(kTrainThreads), lds, st, one,
                                    many, T, lr, beta1, beta2, eps, S, lds_floats, gl);
             }
             return (int)hipGetLastError();
@@ -972,23 +988,26 @@ int launch_maml_train(const mvn_train_trial_t &one, const mvn_train_trial_t *man
         });
     }
     const size_t ws_floats_one = maml_groups_workspace_bytes(S, groups) / sizeof(float);
-    const int per_launch = many ? trials_per_launch(R, cus / groups) : 1;
+    const bool xcd = xcd_grid(groups, cus, R);
+    const int per_launch = many ? trials_per_launch(R, group_trials_fit(groups, cus, R)) : 1;
     for (int r0 = 0; r0 < R; r0 += per_launch) {
         const int nr = std::min(per_launch, R - r0);
         float *wsr = (float *)workspace + (size_t)r0 * stride;
         hipError_t e = clear_group_syncs(wsr, stride, nr, st);
         if (e != hipSuccess) return (int)e;
-        const GroupLaunch gl = {wsr, (long long)stride, (unsigned)((many ? stride : ws_floats_one) * sizeof(float)), group_spin_limit(), group_phantoms()};
+        const GroupLaunch gl = {wsr, (long long)stride, (unsigned)((many ? stride : ws_floats_one) * sizeof(float)), group_spin_limit(), group_phantoms(),
+                                xcd ? groups : 0, nr};
+        const dim3 grid = xcd ? dim3(group_grid_blocks(groups, nr)) : dim3((unsigned)groups, (unsigned)nr);
         const int rc = dispatch_states(S, many != nullptr, [&](auto sc) -> int {
             constexpr int SC = decltype(sc)::value;
             if (many) {
                 if (int e2 = ensure_dynamic_lds((const void *)maml_train_groups_kernel<SC == 32 ? 0 : SC, true>, lds)) return e2;
-                hipLaunchKernelGGL((maml_train_groups_kernel<SC == 32 ? 0 : SC, true>), dim3((unsigned)groups, (unsigned)nr),
+                hipLaunchKernelGGL((maml_train_groups_kernel<SC == 32 ? 0 : SC, true>), grid,
                                    dim3(kTrainThreads), lds, st, one, many + r0, T, W, meta_lr, second_order, lr, beta1, beta2, eps, S,
                                    lds_floats, gl);
             } else {
                 if (int e2 = ensure_dynamic_lds((const void *)maml_train_groups_kernel<SC, false>, lds)) return e2;
-                hipLaunchKernelGGL((maml_train_groups_kernel<SC, false>), dim3((unsigned)groups), dim3(kTrainThreads), lds, st, one,
+                hipLaunchKernelGGL((maml_train_groups_kernel<SC, false>), grid, dim3(kTrainThreads), lds, st, one,
                                    many, T, W, meta_lr, second_order, lr, beta1, beta2, eps, S, lds_floats, gl);
             }
             return (int)hipGetLastError();
@@ -1305,13 +1324,14 @@ int mvn_vnet_train_kernel_name(int32_t kind, int32_t R, int32_t T, int32_t M_or_
     } else if (!groups) {
         snprintf(name, (size_t)name_len, "%s_kernel<%d, %s> 1x%d", base, sc, many ? "true" : "false", n_trials);
     } else {
-        const int per_launch = many ? trials_per_launch(n_trials, current_device_cus() / groups) : 1;
+        const int per_launch = many ? trials_per_launch(n_trials, group_trials_fit(groups, current_device_cus(), n_trials)) : 1;
         const int launches = (n_trials + per_launch - 1) / per_launch;
+        const char *place = xcd_grid(groups, current_device_cus(), n_trials) ? " one XCD per trial" : "";
         if (launches > 1)
-            snprintf(name, (size_t)name_len, "%s_groups_kernel<%d, %s> %dx%d in %d launches", base, sc, many ? "true" : "false", groups,
-                     per_launch, launches);
+            snprintf(name, (size_t)name_len, "%s_groups_kernel<%d, %s> %dx%d in %d launches%s", base, sc, many ? "true" : "false", groups,
+                     per_launch, launches, place);
         else
-            snprintf(name, (size_t)name_len, "%s_groups_kernel<%d, %s> %dx%d", base, sc, many ? "true" : "false", groups, per_launch);
+            snprintf(name, (size_t)name_len, "%s_groups_kernel<%d, %s> %dx%d%s", base, sc, many ? "true" : "false", groups, per_launch, place);
     }
     return MVN_OK;
 }

@@ -1086,15 +1086,18 @@ def test_online_training_groups_equal_single_workgroup(dev, monkeypatch, S, T):
     tx = torch.tensor(rng.randint(0, 2, (1, T)).astype(np.float32), device=dev)
     y = torch.tensor(rng.normal(0, 1.5, (1, T)).astype(np.float32), device=dev)
     out = []
-    for groups in ("1", "0"):
+    # chunked on the XCD-aware grid (a trial's workgroups on one XCD, exchange through its L2: the default), chunked on the
+    # (groups, trials) grid (write-through exchange across XCDs, MVN_TRAIN_XCD=0), one workgroup
+    for groups, xcd in (("1", "1"), ("1", "0"), ("0", "1")):
         monkeypatch.setenv("MVN_TRAIN_GROUPS", groups)
+        monkeypatch.setenv("MVN_TRAIN_XCD", xcd)
         det = _vnet_with(w, S, T, dev)
         tr = mvn.OnlineTrainer(det, L)
         l1 = tr.online_training(tx, y, iterations=7, full_word=True, return_loss=True)
         l2 = tr.online_training(tx, y, iterations=5, full_word=True, return_loss=True)
         out.append([p.detach().clone() for p in det.parameters()] + [tr.exp_avg.clone(), tr.exp_avg_sq.clone(), l1, l2])
-    for a, b in zip(*out):
-        assert torch.equal(a, b)
+    for a, b, c in zip(*out):
+        assert torch.equal(a, b) and torch.equal(a, c)
     assert bool(torch.isfinite(out[0][-1]).all())
 
 
@@ -1113,15 +1116,16 @@ def test_maml_training_groups_equal_single_workgroup(dev, monkeypatch, S, T, W, 
     sup = torch.stack([torch.arange(k, k + W, device=dev) % 6 for k in range(n_steps)])
     qry = (torch.arange(n_steps, device=dev) + W) % 6
     out = []
-    for groups in ("1", "0"):
+    for groups, xcd in (("1", "1"), ("1", "0"), ("0", "1")):  # as in the test above
         monkeypatch.setenv("MVN_TRAIN_GROUPS", groups)
+        monkeypatch.setenv("MVN_TRAIN_XCD", xcd)
         det = _vnet_with(w, S, T, dev)
         tr = mvn.OnlineTrainer(det, L)
         l1 = tr.maml_training(rxw, txw, sup, qry, 0.1, MAML, return_loss=True)
         l2 = tr.maml_training(rxw, txw, sup[:2], qry[:2], 0.1, MAML, return_loss=True)
         out.append([p.detach().clone() for p in det.parameters()] + [tr.exp_avg.clone(), tr.exp_avg_sq.clone(), l1, l2])
-    for a, b in zip(*out):
-        assert torch.equal(a, b)
+    for a, b, c in zip(*out):
+        assert torch.equal(a, b) and torch.equal(a, c)
     assert bool(torch.isfinite(out[0][-1]).all()) and bool(torch.isfinite(out[0][0]).all())
 
 
@@ -1552,3 +1556,28 @@ def test_eval_by_word_buffer_and_weights_init_variants(golden, dev):
     with pytest.raises(ValueError):
         mvn.eval_by_word(_vnet_with(w, 16, 136, dev), msg, rx, 10.0, 0.2, 2, 25, self_supervised=True,
                          online_trainer=mvn.OnlineTrainer(_vnet_with(w, 16, 136, dev), 4), weights_init="nope")
+
+
+def test_chunked_training_finds_its_workgroups_on_one_xcd(dev, monkeypatch):
+    """The chunked training launches use a grid that puts a trial's workgroups on ONE XCD (blocks b and b + 8 share an XCD:
+    observed dispatch order, not a promise), and the workgroups establish from HW_REG_XCC_ID whether that held: only then does the
+    gradient exchange stay in the XCD's L2 (plain stores, L2 arrival counter), otherwise it is the write-through exchange.
+    GroupSync.placement (word 33 of the trial's workspace) records what they found: 1 on this hardware with the default grid,
+    2 with MVN_TRAIN_XCD=0 (the (groups, trials) grid deals a trial's 5 workgroups to 5 XCDs).  Results are identical either
+    way (test_*_groups_equal_single_workgroup); this test pins that the fast path is the one that runs."""
+    rng = np.random.RandomState(5)
+    w = _rand_weights(16, rng)
+    tx = torch.tensor(rng.randint(0, 2, (1, 136)).astype(np.float32), device=dev)
+    y = torch.tensor(rng.normal(0, 1.5, (1, 136)).astype(np.float32), device=dev)
+    found = {}
+    for xcd in ("1", "0"):
+        monkeypatch.setenv("MVN_TRAIN_XCD", xcd)
+        det = _vnet_with(w, 16, 136, dev)
+        tr = mvn.OnlineTrainer(det, 4)
+        tr.online_training(tx, y, iterations=3, full_word=True)
+        torch.cuda.synchronize()
+        sync = tr._ws[:256].view(torch.int32).cpu().numpy()
+        found[xcd] = (int(sync[33]), int(sync[2]))  # placement, xcc_mask
+        assert sync[1] == 0  # no abandoned barrier
+    assert found["1"][0] == 1 and bin(found["1"][1]).count("1") == 1, found
+    assert found["0"][0] == 0 and bin(found["0"][1]).count("1") == 5, found  # (the spread grid never asks: placement stays 0)

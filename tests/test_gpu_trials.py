@@ -208,13 +208,17 @@ def _train_kernel_name(kind, R, T, M_or_W, S, ws_bytes):
 
 
 # The launcher's forms of the trial-batched training kernels (mvn_hip.hip: plan_online_groups / plan_maml_groups):
-#   chunked   -- one workgroup per 32-sample chunk AND trial: *_train_groups_kernel<SC, true> (the launcher's choice for few trials)
+#   chunked   -- one workgroup per 32-sample chunk AND trial: *_train_groups_kernel<SC, true> (the launcher's choice for few trials),
+#                on the XCD-aware grid: a trial's workgroups on one XCD, gradient exchange through its L2 ("one XCD per trial")
+#   chunked_spread -- the same kernels on the (groups, trials) grid: a trial's workgroups on different XCDs, write-through exchange
+#                (what the launcher keeps where the XCD-aware grid would need more launches); MVN_TRAIN_XCD=0
 #   per_trial -- one workgroup per trial: online_train_kernel<SC, true> with M = 0, maml_train_kernel<SC, true> -- the launcher's
 #                choice from ~154 trials on, i.e. what bench.py times at 256 trials; forced here with MVN_TRAIN_GROUPS=0
 #   pair      -- one 512-thread workgroup per trial, two of them per CU (online_train_kernel<SC, true, 512>: the launcher's choice
 #                for more trials than CUs; Adam moments in global memory, every wave two roles per phase); MVN_TRAIN_PAIR=1
 FORMS = {"chunked": {"MVN_TRAIN_GROUPS": "1", "MVN_TRAIN_PAIR": "0"}, "per_trial": {"MVN_TRAIN_GROUPS": "0", "MVN_TRAIN_PAIR": "0"},
-         "pair": {"MVN_TRAIN_GROUPS": "0", "MVN_TRAIN_PAIR": "1"}}
+         "pair": {"MVN_TRAIN_GROUPS": "0", "MVN_TRAIN_PAIR": "1"},
+         "chunked_spread": {"MVN_TRAIN_GROUPS": "1", "MVN_TRAIN_PAIR": "0", "MVN_TRAIN_XCD": "0"}}
 _SEQUENTIAL = {}
 
 
@@ -249,14 +253,14 @@ def test_batched_trials_equal_sequential_runs(golden, dev, monkeypatch, flow, fo
     snrs = [6.0, 7.0, 8.0, 9.0, 10.0, 11.0, 12.0]
     w = _trial_weights(golden, R, seed=3)
     msg, rx = _words(dev, R, N, K, nsym, snrs, seed=11)
-    for name in ("MVN_TRAIN_GROUPS", "MVN_TRAIN_PAIR"):
+    for name in ("MVN_TRAIN_GROUPS", "MVN_TRAIN_PAIR", "MVN_TRAIN_XCD"):
         monkeypatch.delenv(name, raising=False)
     seq = _sequential_runs(golden, dev, flow, R, N, K, nsym, sub, snrs, w, msg, rx, 100)
     for name, value in FORMS[form].items():
         monkeypatch.setenv(name, value)
     W = kw.get("window_size", 1)
     ws_bytes = int(mvn._lib.load().mvn_vnet_train_trials_workspace_bytes(16, T, W, R))
-    tag = "_groups_kernel<16, true>" if form == "chunked" else "_kernel<16, true> 1x"
+    tag = "_groups_kernel<16, true>" if form.startswith("chunked") else "_kernel<16, true> 1x"
     online_tag = "_kernel<16, true, 512> 1x" if form == "pair" else tag
     if kw.get("meta_style_online_training"):  # full-word iterations
         assert online_tag in _train_kernel_name(0, R, T, 0, 16, ws_bytes)
@@ -524,7 +528,8 @@ def test_trial_entry_points_for_other_state_counts(dev, monkeypatch, S, T, form)
         if mode != "minibatch":  # the run-time-S instantiations, in the form asked for
             named = _train_kernel_name(2 if mode == "maml" else 0, R, T, 1 if mode == "maml" else 0, S, nb)
             # (the two-trials-per-CU form exists for 16 states only: asked for here, it must not be taken)
-            assert ("_groups_kernel<0, true>" if form == "chunked" else "_kernel<0, true> 1x") in named, named
+            assert ("_groups_kernel<0, true>" if form.startswith("chunked") else "_kernel<0, true> 1x") in named, named
+            assert ("one XCD per trial" in named) == (form == "chunked"), named
         if mode == "maml":
             rc = lib.mvn_vnet_maml_train_trials_f32(mvn._lib.ptr(dd), R, T, 1, 0.1, 1, 1e-3, 0.9, 0.999, 1e-8, S, mvn._lib.ptr(wsb), nb,
                                                     mvn._lib.current_stream(dev))

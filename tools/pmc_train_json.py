@@ -14,8 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 table, reps, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 # prof_train_kernels.py's CASES, in launch order: (name, kernel, trials, iterations per launch)
 CASES = [("online_minibatch", "online_train_kernel<16, true, 1024>", 256, 200), ("online_full_word", "online_train_kernel<16, true, 1024>", 256, 200),
-         ("online_full_word_chunked", "online_train_groups_kernel<16, true>", 51, 200), ("maml_second_order", "maml_train_kernel<16, true>", 256, 40),
-         ("maml_second_order_chunked", "maml_train_groups_kernel<16, true>", 51, 40)]
+         ("online_full_word_chunked", "online_train_groups_kernel<16, true>", 48, 200), ("maml_second_order", "maml_train_kernel<16, true>", 256, 40),
+         ("maml_second_order_chunked", "maml_train_groups_kernel<16, true>", 48, 40)]
 
 
 def csrc_sha16():

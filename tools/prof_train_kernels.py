@@ -2,9 +2,9 @@
 run them, each launched a few times through the C ABI's trial entry points (hand-filled descriptors, like a C caller):
     online_train_kernel<16, true>         256 trials x 200 minibatch iterations (32 samples)        grid 1x256
     online_train_kernel<16, true>         256 trials x 200 full-word iterations (136 samples)       grid 1x256
-    online_train_groups_kernel<16, true>   51 trials x 200 full-word iterations, 5 workgroups each  grid 5x51
+    online_train_groups_kernel<16, true>   48 trials x 200 full-word iterations, 5 workgroups each  grid 5x48, a trial's workgroups on one XCD
     maml_train_kernel<16, true>           256 trials x 40 second-order meta-learning steps          grid 1x256
-    maml_train_groups_kernel<16, true>     51 trials x 40 steps, 5 workgroups each                  grid 5x51
+    maml_train_groups_kernel<16, true>     48 trials x 40 steps, 5 workgroups each                  grid 5x48, a trial's workgroups on one XCD
 Prints each launch's wall time (HIP events) and the algorithmic FLOPs, so that a --pmc pass can be turned into a roofline
 entry (tools/pmc_train_summary.py).  usage: prof_train_kernels.py [reps]"""
 import os
@@ -74,8 +74,8 @@ def run(kind, R, n, M=0, second_order=1):
 
 # algorithmic FLOPs (bench.py's training_roofline): 35 kFLOP per sample of a CE forward + backward pass; a second-order step =
 # support + query gradient passes + a Hessian-vector pass of ~3 gradient passes over the support word
-CASES = [("online", 256, 200, 32, 1, 35e3 * 32), ("online", 256, 200, 0, 1, 35e3 * T), ("online", 51, 200, 0, 1, 35e3 * T),
-         ("maml", 256, 40, 0, 1, 35e3 * 2 * T + 105e3 * T), ("maml", 51, 40, 0, 1, 35e3 * 2 * T + 105e3 * T)]
+CASES = [("online", 256, 200, 32, 1, 35e3 * 32), ("online", 256, 200, 0, 1, 35e3 * T), ("online", 48, 200, 0, 1, 35e3 * T),
+         ("maml", 256, 40, 0, 1, 35e3 * 2 * T + 105e3 * T), ("maml", 48, 40, 0, 1, 35e3 * 2 * T + 105e3 * T)]
 print("kernel_form,trials,iterations,samples_per_iteration,ms_per_launch,us_per_iteration_per_trial_slot,algorithmic_TFLOPs")
 for kind, R, n, M, so, flop_it in CASES:
     ms, form = run(kind, R, n, M, so)
