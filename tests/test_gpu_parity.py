@@ -1562,7 +1562,7 @@ def test_chunked_training_finds_its_workgroups_on_one_xcd(dev, monkeypatch):
     """The chunked training launches use a grid that puts a trial's workgroups on ONE XCD (blocks b and b + 8 share an XCD:
     observed dispatch order, not a promise), and the workgroups establish from HW_REG_XCC_ID whether that held: only then does the
     gradient exchange stay in the XCD's L2 (plain stores, L2 arrival counter), otherwise it is the write-through exchange.
-    GroupSync.placement (word 33 of the trial's workspace) records what they found: 1 on this hardware with the default grid,
+    GroupSync.placement (word 64 of the trial's workspace) records what they found: 1 on this hardware with the default grid,
     2 with MVN_TRAIN_XCD=0 (the (groups, trials) grid deals a trial's 5 workgroups to 5 XCDs).  Results are identical either
     way (test_*_groups_equal_single_workgroup); this test pins that the fast path is the one that runs."""
     rng = np.random.RandomState(5)
@@ -1576,8 +1576,8 @@ def test_chunked_training_finds_its_workgroups_on_one_xcd(dev, monkeypatch):
         tr = mvn.OnlineTrainer(det, 4)
         tr.online_training(tx, y, iterations=3, full_word=True)
         torch.cuda.synchronize()
-        sync = tr._ws[:256].view(torch.int32).cpu().numpy()
-        found[xcd] = (int(sync[33]), int(sync[2]))  # placement, xcc_mask
+        sync = tr._ws[:384].view(torch.int32).cpu().numpy()
+        found[xcd] = (int(sync[64]), int(sync[2]))  # placement, xcc_mask
         assert sync[1] == 0  # no abandoned barrier
     assert found["1"][0] == 1 and bin(found["1"][1]).count("1") == 1, found
     assert found["0"][0] == 0 and bin(found["0"][1]).count("1") == 5, found  # (the spread grid never asks: placement stays 0)
