@@ -277,8 +277,10 @@ int mvn_vnet_maml_train_trials_f32(const mvn_train_trial_t *trials, int32_t R, i
  *   R: 0 = the single-trial entry points, > 0 = the *_trials_* entry points with R trials that run (n > 0);
  *   M_or_W: minibatch size M (0 = whole word) for kind 0, support words W for kinds 1, 2;
  *   workspace_bytes: what the call passes (0 = no workspace).
- * name (HOST pointer) receives e.g. "maml_train_kernel<16, true> 1x176" or "online_train_groups_kernel<16, true> 5x51 in 4
- * launches" (workgroups per trial x trials per launch).  Returns 0, MVN_E_DIMS, MVN_E_STATES or MVN_E_NULL.
+ * name (HOST pointer) receives e.g. "maml_train_kernel<16, true> 1x176" or "online_train_groups_kernel<16, true> 5x48 in 2
+ * launches one XCD per trial" (workgroups per trial x trials per launch; "one XCD per trial": the grid that places a trial's
+ * workgroups on one XCD so that their gradient exchange stays in its L2 -- MVN_TRAIN_XCD=0 keeps the (groups, trials) grid).
+ * Returns 0, MVN_E_DIMS, MVN_E_STATES or MVN_E_NULL.
  */
 int mvn_vnet_train_kernel_name(int32_t kind, int32_t R, int32_t T, int32_t M_or_W, int32_t S, size_t workspace_bytes, char *name,
                                int32_t name_len);
