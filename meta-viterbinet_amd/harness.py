@@ -15,6 +15,7 @@ import torch.distributed as dist
 from . import metrics as _metrics
 from .channel import estimate_channel, transmit
 from .ecc import rs_decode, rs_encode
+from .trellis import calculate_states
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -275,12 +276,33 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
             return torch.unique(torch.randint(low=0, high=high, size=[meta_j_num])).to(rx.device)
         return torch.as_tensor(draws.j_hat(high, meta_j_num), device=rx.device).long()
 
-    nerr1 = torch.zeros(1, dtype=torch.int32, device=rx.device) if fused else None
+    from .detectors import VNETDetector
+
+    # The fused ViterbiNet step also picks the word the reference buffers and computes its trellis states (what the training
+    # kernels take as labels), and the block's error count travels to the host together with the trainer's status word: one
+    # launch and one 8-byte copy per block before the host decides.
+    step_labels = fused and isinstance(detector, VNETDetector) and online_trainer is not None and online_trainer.use_kernel
+    sync_words = online_trainer.sync_words if (step_labels and getattr(online_trainer, "sync_words", None) is not None) else None
+    nerr1 = (sync_words[:1] if sync_words is not None else torch.zeros(1, dtype=torch.int32, device=rx.device)) if fused else None
+    buffer_lab = None
+    if step_labels:
+        buffer_lab = (torch.empty([0, rx.shape[1]], dtype=torch.int32, device=rx.device) if buffer_empty else
+                      calculate_states(online_trainer.memory_length, buffer_tx).reshape(buffer_tx.shape).to(torch.int32))
     for count in range(N):
         transmitted_word, received_word = tx[count].reshape(1, -1), rx[count].reshape(1, -1)
         pilot = count % subframes_in_frame == 0
         seen = {"count": count, "meta": None, "trained": False, "batch_idx": None} if observer is not None else None
-        if fused:  # ONE launch: detect, RS decode, error count, re-encode (pilot: encode the known word)
+        status_word = None
+        if step_labels:  # ONE launch: detect, RS decode, error count, re-encode, the word to buffer and its states
+            label_word, label_states = _byword_step(detector, received_word, transmitted_word, n_symbols, pilot, nerr1, labels=True)
+            if sync_words is not None:
+                n_err, status_word = sync_words.tolist()
+            else:
+                n_err = int(nerr1.item())
+            ser = 0.0 if pilot else float(_metrics.ser_from_errors(n_err, K))  # calculate_error_rates (:301)
+            if not pilot:
+                ser_by_word[count] = ser
+        elif fused:  # ONE launch: detect, RS decode, error count, re-encode (pilot: encode the known word)
             detected_word, encoded_word = _byword_step(detector, received_word, transmitted_word, n_symbols, pilot, nerr1,
                                                        gamma=gamma, count=count if pass_count else None)
             ser = 0.0 if pilot else float(_metrics.ser_from_errors(int(nerr1.item()), K))  # calculate_error_rates (:301)
@@ -297,14 +319,20 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
                 encoded_word = rs_encode(transmitted_word, n_symbols)  # pilot: the word is known (:314-316)
                 ser = 0.0
         if online_trainer is not None:
-            online_trainer.check_status()  # a training launch that gave up its barrier (NaN weights) raises here
+            online_trainer.check_status(status_word)  # a training launch that gave up its barrier (NaN weights) raises here
         if verbose:
             print(f"current: {count, ser}")
         if ser <= ser_thresh:  # :319-329 (buffer_empty=True: the buffer only grows)
             buffer_rx = torch.cat([buffer_rx, received_word])
-            buffer_tx = torch.cat([buffer_tx, detected_word.reshape(1, -1) if ser > 0 else encoded_word.reshape(1, -1)], dim=0)
+            if step_labels:
+                buffer_tx = torch.cat([buffer_tx, label_word], dim=0)
+                buffer_lab = torch.cat([buffer_lab, label_states], dim=0)
+            else:
+                buffer_tx = torch.cat([buffer_tx, detected_word.reshape(1, -1) if ser > 0 else encoded_word.reshape(1, -1)], dim=0)
             if not buffer_empty:  # fixed-length window: the oldest word leaves (:325-328)
                 buffer_rx, buffer_tx = buffer_rx[1:], buffer_tx[1:]
+                if step_labels:
+                    buffer_lab = buffer_lab[1:].contiguous()
         if online_meta and count % meta_subframes == 0 and count >= meta_subframes and buffer_rx.shape[0] > 2:  # :331-343
             if weights_init == "last_frame":  # meta_weights_init (:356-366)
                 copy_model(source_model=saved_detector, dest_model=detector)
@@ -330,7 +358,7 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
                     j_all = torch.cat([draw_j_hat(buffer_rx.shape[0] - 2) for _ in range(meta_train_iterations)])
                 sup_all = j_all.reshape(-1, 1) + support_idx.reshape(1, -1) + 1
                 qry_all = j_all + query_idx + 1
-                online_trainer.maml_training(buffer_rx, buffer_tx, sup_all, qry_all, meta_lr, MAML)
+                online_trainer.maml_training(buffer_rx, buffer_tx, sup_all, qry_all, meta_lr, MAML, labels=buffer_lab)
                 if seen is not None:
                     seen["meta"] = (sup_all, qry_all)
             else:
@@ -364,7 +392,8 @@ def eval_by_word(detector, tx: torch.Tensor, rx: torch.Tensor, snr: float, gamma
                 batch_idx = online_trainer.select_batches(rx.shape[1], self_supervised_iterations)  # drawn here to be shown
             online_trainer.online_training(buffer_tx[-1].reshape(1, -1), buffer_rx[-1].reshape(1, -1),
                                            iterations=self_supervised_iterations, batch_idx=batch_idx,
-                                           full_word=meta_style_online_training)
+                                           full_word=meta_style_online_training,
+                                           labels=None if buffer_lab is None else buffer_lab[-1])
             if seen is not None:
                 seen.update(trained=True, batch_idx=batch_idx)
         if seen is not None:
@@ -392,11 +421,14 @@ def _fused_step_applies(detector, rx: torch.Tensor, n_symbols: int, pass_count: 
 
 
 def _byword_step(detector, received_word: torch.Tensor, transmitted_word: torch.Tensor, n_symbols: int, pilot: bool,
-                 nerr: torch.Tensor, outputs: bool = True, gamma: float = None, count: int = None):
+                 nerr: torch.Tensor, outputs: bool = True, gamma: float = None, count: int = None, labels: bool = False):
     """One block of eval_by_word in one launch (trainer.py:292-316): returns (detected_word, encoded_word) [1, T]; the
     block's bit-error count goes to nerr[0] (device int32).  On a pilot the detection is skipped (never used) and
     detected_word is None.  outputs=False: the error count only (no words are stored, the re-encoding is skipped).
-    gamma / count: what VADetector.forward takes to find the word's channel (count None: the detector's single table row)."""
+    gamma / count: what VADetector.forward takes to find the word's channel (count None: the detector's single table row).
+    labels=True (ViterbiNet): returns (label_word [1, T], states int32 [1, T]) instead -- the word the reference pushes into its
+    buffer (:322-324: the detected word if it had bit errors, else the re-encoded one) and its trellis states, both chosen and
+    computed by the kernel."""
     from . import _lib
     from .detectors import VADetector
 
@@ -416,6 +448,15 @@ def _byword_step(detector, received_word: torch.Tensor, transmitted_word: torch.
         _lib.check(rc, "mvn_va_byword_step_f32")
         return det, enc
     w = detector._params()
+    if labels:
+        word, states = torch.empty((1, T), dtype=torch.float32, device=dev), torch.empty((1, T), dtype=torch.int32, device=dev)
+        with _lib.on_device(dev):
+            rc = _lib.load().mvn_vnet_byword_step_f32(_lib.ptr(rxw), T, _lib.ptr(txw), K, *[_lib.ptr(_lib.f32c(p)) for p in w], None,
+                                                      None, T, None, K, None, T, _lib.ptr(word), T, _lib.ptr(states), T,
+                                                      _lib.ptr(nerr), 1, T, n_symbols, 1 if pilot else 0, 16,
+                                                      _lib.current_stream(dev))
+        _lib.check(rc, "mvn_vnet_byword_step_f32")
+        return word, states
     with _lib.on_device(dev):
         rc = _lib.load().mvn_vnet_byword_step_f32(_lib.ptr(rxw), T, _lib.ptr(txw), K, *[_lib.ptr(_lib.f32c(p)) for p in w], None,
                                                   _lib.ptr(det), T, None, K, _lib.ptr(enc), T, None, T, None, T,

@@ -29,8 +29,11 @@ class OnlineTrainer:
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step = 0
-        # set to 1 by a training launch whose device-wide barrier gave up (include/mvn.h); read by check_status()
-        self.status = torch.zeros(1, dtype=torch.int32, device=dev) if dev.type == "cuda" else None
+        # set to 1 by a training launch whose device-wide barrier gave up (include/mvn.h); read by check_status().  It is the
+        # second of two words: the first is free for the caller's per-block error count (harness.eval_by_word), so that ONE
+        # device-to-host copy per block brings both (sync_words)
+        self.sync_words = torch.zeros(2, dtype=torch.int32, device=dev) if dev.type == "cuda" else None
+        self.status = self.sync_words[1:2] if dev.type == "cuda" else None
         self._unchecked = False
 
     def reset_state(self):
@@ -39,14 +42,15 @@ class OnlineTrainer:
         self.exp_avg_sq.zero_()
         self.step = 0
 
-    def check_status(self):
+    def check_status(self, value=None):
         """Raises MvnError if a training launch since the last check abandoned its device-wide barrier (its weights are NaN):
         the counterpart of the reference's NaN guard (trainer.py:496-498), which prints and skips the step.  Costs one
         4-byte device-to-host copy, and only when a kernel launch is outstanding: call it where the host synchronises anyway
-        (harness.eval_by_word does after every block's `ser`)."""
+        (harness.eval_by_word does after every block's `ser`).  value: the status word when the caller has just read it
+        (sync_words[1], together with its own word) -- no copy then."""
         if self._unchecked and self.status is not None:
             self._unchecked = False
-            if int(self.status.item()) != 0:
+            if int(self.status.item() if value is None else value) != 0:
                 self.status.zero_()
                 raise _lib.MvnError("OnlineTrainer: " + _lib.load().mvn_strerror(-7).decode())
 
@@ -109,18 +113,23 @@ class OnlineTrainer:
             off += n
 
     def maml_training(self, rx_words: torch.Tensor, tx_words: torch.Tensor, support_idx: torch.Tensor,
-                      query_idx: torch.Tensor, meta_lr: float, MAML: bool = True, return_loss: bool = False):
+                      query_idx: torch.Tensor, meta_lr: float, MAML: bool = True, return_loss: bool = False, labels: torch.Tensor = None):
         """n online meta-learning steps (trainer.py:425-453 = meta.meta_train_loop) in ONE kernel launch.
         rx_words / tx_words [Nw, T]: buffered received words and their (re-encoded or detected) transmitted words;
         support_idx [n, W], query_idx [n]: the words of every step (negative indices count from the end, like the
-        reference's fancy indexing).  Uses and advances the same Adam state as online_training."""
+        reference's fancy indexing).  Uses and advances the same Adam state as online_training.
+        labels: int32 [Nw, T], the trellis states of tx_words when the caller already has them (the block-step kernel writes them
+        next to the word it buffers); None: calculate_states(tx_words)."""
         p = self.params
         dev = p[0].device
         _lib.require_gpu_tensor(rx_words, "rx_words")
         _lib.require_gpu_tensor(p[0], "detector parameters")
         rx = rx_words.detach().to(torch.float32).contiguous()
         Nw, T = rx.shape
-        labels = calculate_states(self.memory_length, tx_words.detach().to(dev)).reshape(Nw, T).to(torch.int32).contiguous()
+        if labels is None:
+            labels = calculate_states(self.memory_length, tx_words.detach().to(dev)).reshape(Nw, T).to(torch.int32).contiguous()
+        elif labels.shape != (Nw, T) or labels.dtype != torch.int32 or not labels.is_contiguous():
+            raise ValueError("labels: contiguous int32 [Nw, T]")
         sup = torch.remainder(support_idx.to(dev).reshape(query_idx.numel(), -1), Nw).to(torch.int32).contiguous()
         qry = torch.remainder(query_idx.to(dev).reshape(-1), Nw).to(torch.int32).contiguous()
         n, W = sup.shape
@@ -157,9 +166,10 @@ class OnlineTrainer:
         return torch.multinomial(w, self.train_minibatch_size).to(torch.int32)
 
     def online_training(self, tx: torch.Tensor, rx: torch.Tensor, iterations: int = 200, batch_idx: torch.Tensor = None,
-                        full_word: bool = False, return_loss: bool = False):
+                        full_word: bool = False, return_loss: bool = False, labels: torch.Tensor = None):
         """tx [1,T] (re-encoded / detected word), rx [1,T] received word (vnet_trainer.py:49-60).
-        full_word=True uses every sample each iteration (the Meta-ViterbiNet variant, metavnet_trainer.py:41-64)."""
+        full_word=True uses every sample each iteration (the Meta-ViterbiNet variant, metavnet_trainer.py:41-64).
+        labels: int32 [T], the trellis states of tx when the caller already has them (kernel route only); None: calculate_states(tx)."""
         p = self.params
         dev = p[0].device
         if p[5].numel() > 32 or not self.use_kernel:  # the one-launch kernel keeps parameters + both Adam moments in LDS: n_states <= 32
@@ -168,7 +178,10 @@ class OnlineTrainer:
         _lib.require_gpu_tensor(p[0], "detector parameters")
         y = rx.detach().to(torch.float32).reshape(-1).contiguous()
         T = y.numel()
-        labels = calculate_states(self.memory_length, tx.detach().to(dev).reshape(1, -1)).to(torch.int32).contiguous()
+        if labels is None:
+            labels = calculate_states(self.memory_length, tx.detach().to(dev).reshape(1, -1)).to(torch.int32).contiguous()
+        elif labels.numel() != T or labels.dtype != torch.int32 or not labels.is_contiguous():
+            raise ValueError("labels: contiguous int32 [T]")
         if full_word:
             idx, M = None, 0
         else:
