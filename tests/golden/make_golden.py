@@ -510,7 +510,7 @@ def _by_word_flow(out, tag, cls, kw, g7, blocks_frames=3):
     out[f"{tag}_tx"] = tx_msg.numpy().astype(np.uint8)
     out[f"{tag}_rx"] = rx.numpy().astype(np.float32)
     out[f"{tag}_ser_by_word"] = np.asarray(ser_by_word, np.float64)
-    out[f"{tag}_multinomial"] = np.array(multinomials, np.int32).reshape(len(multinomials), -1 if multinomials else 0)
+    out[f"{tag}_multinomial"] = np.array(multinomials, np.uint8 if rx.shape[1] <= 256 else np.int32).reshape(len(multinomials), -1 if multinomials else 0)
     out[f"{tag}_randint_high"] = np.array([h for h, _ in randints], np.int64)
     out[f"{tag}_randint"] = np.array([v for _, v in randints], np.int64).reshape(len(randints), -1 if randints else 0)
     if inits:
@@ -562,6 +562,24 @@ def g13_by_word_switches():
     _by_word_flow(out, "sgd", VNETTrainer, dict(self_supervised=True, self_supervised_iterations=6, online_meta=False,
                                                 optimizer_type="SGD", lr=0.05), g7, 2)
     save("g13_by_word_switches", **out)
+
+
+def g15_by_word_reference_defaults():
+    """BASELINE configs[2] and configs[4] WITH their updates at the reference's own hyperparameters (config.yaml: 200 self-supervised
+    iterations per block; meta-learning every 5 blocks, 20 iterations x 10 drawn pairs, meta_lr 0.1, second order), 50 blocks each,
+    run by the unmodified reference and recorded like G12: (a) VNETTrainer over the COST2100 taps, 200 minibatch CE + Adam
+    iterations after every qualifying block (9 600 Adam steps); (b) METAVNETTrainer over the fading synthetic channel, 200
+    whole-word iterations per block from the saved weights + 9 meta-learning updates of up to 200 second-order steps."""
+    from python_code.trainers.META_VNET.metavnet_trainer import METAVNETTrainer
+
+    g7 = np.load(os.path.join(HERE, "g7_by_word.npz"))
+    out = {}
+    _by_word_flow(out, "c2_selfsup", VNETTrainer, dict(self_supervised=True, self_supervised_iterations=200, online_meta=False,
+                                                       channel_coefficients="cost2100", fading_in_channel=False), g7, 2)
+    _by_word_flow(out, "c4_meta", METAVNETTrainer, dict(self_supervised=True, self_supervised_iterations=200, online_meta=True, MAML=True,
+                                                        meta_lr=0.1, window_size=1, meta_train_iterations=20, meta_j_num=10,
+                                                        meta_subframes=5, weights_init="last_frame"), g7, 2)
+    save("g15_by_word_reference_defaults", **out)
 
 
 # ----------------------------------------------------------------------------- G14
@@ -662,14 +680,15 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g14":
         g14_aggregated_evaluate()
+        g15_by_word_reference_defaults()
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] in ("g12", "g13"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("g12", "g13", "g15"):
         import contextlib
         import io
 
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):  # (the reference prints every block)
-            g12_by_word_with_updates() if sys.argv[1] == "g12" else g13_by_word_switches()
+            {"g12": g12_by_word_with_updates, "g13": g13_by_word_switches, "g15": g15_by_word_reference_defaults}[sys.argv[1]]()
         print("\n".join(l for l in buf.getvalue().splitlines() if l.startswith(("g12", "wrote"))))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g10":

@@ -27,12 +27,16 @@ def dev():
 class RecordedDraws:
     """trials.TrialDraws' interface over the draws the reference made (in its call order)."""
 
+    lenient = False  # True: past the end of the recording (a run that has parted from the reference) the last draws repeat
+
     def __init__(self, multinomial, randint_high, randint, device, init_weights=None):
         self.multinomial, self.randint_high, self.randint, self.device = multinomial, randint_high, randint, device
         self.inits = np.zeros((0, 0), np.float32) if init_weights is None else init_weights
         self.m_at = self.r_at = self.i_at = 0
 
     def batches(self, count, n_blocks, T, iterations, M):
+        if self.lenient and self.m_at + iterations > len(self.multinomial):
+            self.m_at = len(self.multinomial) - iterations
         rows = self.multinomial[self.m_at:self.m_at + iterations]
         if rows.shape != (iterations, M):
             raise AssertionError(f"block {count} trains, the reference's recorded minibatches are used up ({self.m_at} of {len(self.multinomial)})")
@@ -47,7 +51,13 @@ class RecordedDraws:
         out = []
         for _ in range(iterations):
             if self.r_at >= len(self.randint):
-                raise AssertionError("a meta-learning update the reference did not make")
+                if not self.lenient:
+                    raise AssertionError("a meta-learning update the reference did not make")
+                self.r_at = len(self.randint) - 1
+            if self.lenient and self.randint_high[self.r_at] != high:  # (the runs have parted: another buffer length)
+                out.append(np.unique(self.randint[self.r_at] % high))
+                self.r_at += 1
+                continue
             assert self.randint_high[self.r_at] == high, (self.r_at, int(self.randint_high[self.r_at]), high)  # same buffer length
             assert self.randint.shape[1] == size
             out.append(np.unique(self.randint[self.r_at]))  # torch.unique(torch.randint(...)) (trainer.py:337)
@@ -72,7 +82,7 @@ class RecordedDraws:
 
 
 # the harness arguments of every recorded flow beyond its iteration counts (tests/golden/make_golden.py: g12 / g13)
-FLOWS = {"selfsup": {}, "meta": dict(online_meta=True), "fomaml": dict(online_meta=True, MAML=False),
+FLOWS = {"selfsup": {}, "meta": dict(online_meta=True), "c2_selfsup": {}, "c4_meta": dict(online_meta=True), "fomaml": dict(online_meta=True, MAML=False),
          "window": dict(online_meta=True, window=True), "random": dict(online_meta=True, weights_init="random"),
          "metatrain": dict(online_meta=True, weights_init="meta_training"), "support2": dict(online_meta=True, window_size=2),
          "rmsprop": dict(optimizer_type="RMSprop"), "sgd": dict(optimizer_type="SGD", lr=0.05)}
@@ -99,7 +109,7 @@ def _recorded(g, tag, dev):
                          g[f"{tag}_init_weights"] if f"{tag}_init_weights" in g.files else None)
 
 
-def _run(g, g7, tag, dev, hip):
+def _run(g, g7, tag, dev, hip, lenient=False):
     tx = torch.tensor(g[f"{tag}_tx"], device=dev).float()
     rx = torch.tensor(g[f"{tag}_rx"], device=dev)
     kw, opt, nsym, subframes = _flow_kwargs(g, g7, tag, dev)
@@ -110,6 +120,7 @@ def _run(g, g7, tag, dev, hip):
             p.copy_(torch.as_tensor(g7[f"w{i}"]))
     tr = mvn.OnlineTrainer(det, 4, use_kernel=hip, **opt)
     draws = _recorded(g, tag, dev)
+    draws.lenient = lenient
     if kw.get("online_meta"):
         kw["meta_detector"] = mvn.META_VNETDetector(16, {"train": T, "val": T})
     last = {}
@@ -173,17 +184,70 @@ def test_reference_by_word_switches(golden, dev, tag, hip):
     print(msg)
 
 
+# blocks of G15 over which every route must reproduce the reference's ser_by_word exactly (measured first differences: c2 block 34
+# on all three routes, c4 none on the HIP kernels / block 44 on stock autograd)
+G15_IDENTICAL_PREFIX = {"c2_selfsup": 30, "c4_meta": 40}
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("tag", ["c2_selfsup", "c4_meta"])
+@pytest.mark.parametrize("route", ["hip_kernels", "torch_autograd", "batched_trials"])
+def test_reference_by_word_flow_at_reference_defaults(golden, dev, tag, route):
+    """Golden G15: BASELINE configs[2] (ViterbiNet over the COST2100 taps, 200 self-supervised minibatch iterations per block) and
+    configs[4] (Meta-ViterbiNet: 200 whole-word iterations per block from the saved weights, every 5 blocks 20 x <= 10 second-order
+    meta-learning steps) at the reference's OWN hyperparameters, 50 blocks at 9 dB, run by the unmodified reference with every draw
+    recorded -- 7 800 and ~11 000 Adam steps on weights that move by 0.8.
+    A free run of that length is where fp32 trajectories of two implementations part (tests/test_gpu_replay.py walks the same
+    flows step by step for that reason): the weights end 0.1 apart, and at some block a word near the decision threshold decodes
+    with one or two bit errors more or less -- after which the runs also train on different blocks.  Stock PyTorch on this GPU
+    ('torch_autograd': torch's own autograd and Adam, no kernel of this repo in the training) parts from the CPU reference the
+    same way, at the same or an earlier block.  Asserted: ser_by_word identical over the first G15_IDENTICAL_PREFIX blocks
+    (30 / 40 of 50; ~6 000 Adam steps; measured 34-35 / 44-50), the first differing block within two bit errors, the mean ser
+    of the 50 blocks within half of the reference's."""
+    from meta_viterbinet_amd.trials import TrialBank, eval_by_word_batched
+
+    g, g7 = golden("g15_by_word_reference_defaults"), golden("g7_by_word")
+    ref = g[f"{tag}_ser_by_word"]
+    if route == "batched_trials":
+        R = 2
+        kw, opt, nsym, subframes = _flow_kwargs(g, g7, tag, dev)
+        tx = torch.tensor(g[f"{tag}_tx"], device=dev).float().unsqueeze(0).repeat(R, 1, 1)
+        rx = torch.tensor(g[f"{tag}_rx"], device=dev).unsqueeze(0).repeat(R, 1, 1)
+        bank = TrialBank([[g7[f"w{i}"] for i in range(6)]] * R, 16, 4, dev)
+        draws = [RecordedTableDraws(g, tag, kw["self_supervised_iterations"], subframes, dev, lenient=True) for _ in range(R)]
+        ser_all = eval_by_word_batched(bank, tx, rx, nsym, subframes, draws, **kw)
+        ser, w = ser_all[0], [t.cpu().numpy() for t in bank.weights(0)]
+        assert np.array_equal(ser_all[1], ser_all[0]) and torch.equal(bank.theta[0], bank.theta[1])
+    else:
+        ser, draws, w, _ = _run(g, g7, tag, dev, route == "hip_kernels", lenient=True)
+    assert ser.shape == ref.shape == (50,)
+    differ = np.flatnonzero(ser != ref)
+    first = int(differ[0]) if len(differ) else 50
+    moved = max(float(np.abs(g[f"{tag}_w1_{i}"] - g7[f"w{i}"]).max()) for i in range(6))
+    worst = max(float(np.abs(w[i] - g[f"{tag}_w1_{i}"]).max()) for i in range(6))
+    print(f"g15 {tag} {route}: ser identical on the first {first} of 50 blocks"
+          + (f" (block {first}: {ser[first]:.4f} vs the reference's {ref[first]:.4f})" if first < 50 else "")
+          + f"; mean ser {ser.mean():.5f} vs {ref.mean():.5f}; weights moved {moved:.3f}, end {worst:.2e} from the reference's")
+    assert first >= G15_IDENTICAL_PREFIX[tag]
+    if first < 50:
+        assert abs(ser[first] - ref[first]) <= 2.5 / 120
+    assert abs(ser.mean() - ref.mean()) <= 0.5 * ref.mean()  # (50 blocks: a handful of bit errors either way after the runs part)
+
+
 class RecordedTableDraws(RecordedDraws):
     """The same recorded draws for trials.eval_by_word_batched, which reads a trial's minibatches from a [blocks, iterations, M]
     table by block number: the reference's rows (call order) are laid at the blocks it trained on — the pilots and the data blocks
     whose ser it reported <= ser_thresh (trainer.py:345).  A run that trains on any other block reads rows of -1 and fails."""
 
-    def __init__(self, g, tag, iterations, subframes, device):
+    def __init__(self, g, tag, iterations, subframes, device, lenient=False):
         super().__init__(g[f"{tag}_multinomial"], g[f"{tag}_randint_high"], g[f"{tag}_randint"], device,
                          g[f"{tag}_init_weights"] if f"{tag}_init_weights" in g.files else None)
+        self.lenient = lenient
         ser = g[f"{tag}_ser_by_word"]
         trained = np.flatnonzero((np.arange(len(ser)) % subframes == 0) | (ser <= 0.02))
         table = np.full((len(ser), iterations, 32), -1, np.int32)
+        if lenient:  # a run that parts from the reference trains on other blocks: valid samples there (1..32), not the -1 trap
+            table[:] = np.arange(1, 33, dtype=np.int32)
         if self.multinomial.size:
             assert len(self.multinomial) == iterations * len(trained)
             table[trained] = self.multinomial.reshape(len(trained), iterations, 32)
