@@ -320,7 +320,7 @@ def _report(name, out, ser, steps):
     print(f"{name}: {out['walked']} of {out['segments']} update segments walked, {out['iterations']} iterations (of {steps} Adam steps); "
           f"HIP vs torch per iteration: worst {out['worst']:.3f} of the tolerance (exp_avg {out['worst_parts'][0]:.3f}, exp_avg_sq "
           f"{out['worst_parts'][1]:.3f}, weights {out['worst_parts'][2]:.3f}) in the iterations within it; {len(out['noisy'])} iterations "
-          f"above it by rounding alone (HIP <= 2 x torch's own distance from float64 + 1: (block, stage, iteration, HIP-torch, HIP-f64, "
+          f"above it by rounding alone (HIP within max(2 x torch's own distance from float64 + 1, 2) tolerances of it: (block, stage, iteration, HIP-torch, HIP-f64, "
           f"torch-f64) {out['noisy'][:8]}); {len(out['crossings'])} ReLU-crossing iterations decided by the float64 assignments "
           f"{out['crossings'][:12]}; referee unprovoked {out['referee_runs']} times, HIP vs float64 worst {out['referee_worst']:.3f}; "
           f"chains not bit-exact: {out['chain_inexact']}; mean ser {ser.mean():.5f}")
