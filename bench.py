@@ -381,18 +381,31 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
     R4 = int(os.environ.get("MVN_BENCH_TRIALS_META", "256"))  # a trial per CU: the library then runs one workgroup per trial
     kw4 = dict(self_supervised=True, self_supervised_iterations=200, online_meta=True, meta_train_iterations=20, meta_j_num=10,
                meta_subframes=5, meta_style_online_training=True)
+    one_trial("time_decay", 0, 200, **kw4)()  # warm (first launches of the meta-learning kernels, workspace), as for configs[2]
     ms41, _ = wall_ms(one_trial("time_decay", 0, 200, **kw4), dev)
     st4 = {}
     run4 = trial_batch("time_decay", 200, st4, **kw4)
     grid4 = reference_grid(run4, st4, 200, T2, True, 5) if rank == 0 else None
     rep4 = mvn.replica_eval(run4, R4 * world, rank=rank, world=world, device=dev if backend == "nccl" else "cpu", batched=True)
     ms4 = max_over_ranks(st4["ms"])
+    roof4 = training_roofline(st4, R4, 200, T2, True, 5)
+    # more trials than CUs: the launcher then runs the whole-word iterations as two 512-thread workgroups per CU
+    R4m = int(os.environ.get("MVN_BENCH_TRIALS_META_MORE", str(2 * n_cu.value)))
+    more4 = None
+    if R4m > R4:
+        mvn.replica_eval(run4, R4m * world, rank=rank, world=world, device=dev if backend == "nccl" else "cpu", batched=True)
+        ms4m = max_over_ranks(st4["ms"])
+        more4 = {"trials_per_gpu": R4m, "ms": ms4m, "ms_per_block_step": ms4m / N, "blocks_per_s": world * R4m * N / (ms4m * 1e-3),
+                 "roofline": training_roofline(st4, R4m, 200, T2, True, 5),
+                 "what": "the same flow with two trials per CU: the whole-word iterations run as two 512-thread workgroups per CU "
+                         "(online_train_kernel<16, true, 512>), the meta-learning steps as two rounds of one workgroup per CU"}
     out.append({"config": "BASELINE configs[4]: Meta-ViterbiNet online retrain + decode, L=4, pilot-aided, 300 blocks (reference defaults: "
                           "200 full-word iterations per block, every 5 blocks 20 x <=10 MAML steps)",
                 "n_gpus": world, "trials_per_gpu": R4, "ms": ms4, "ms_per_block_step": ms4 / N, "blocks_per_s": world * R4 * N / (ms4 * 1e-3),
                 "symbols_per_s": world * R4 * N * T2 / (ms4 * 1e-3),
                 "one_trial": {"ms": ms41, "ms_per_block": ms41 / N, "blocks_per_s": N / (ms41 * 1e-3)},
                 "reference_grid": grid4,
+                "more_trials_than_cus": more4,
                 "speedup_vs_one_trial_at_a_time": (R4 * N / ms4) / (N / ms41),
                 "mean_ser_by_snr_db": {str(7 + k): float(np.nanmean(rep4[k::6])) for k in range(6)},
                 "kernel": "maml_train(_groups)_kernel + online_train(_groups)_kernel + byword_step_kernel",
@@ -401,7 +414,7 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
                         "the meta-learning and the online-training kernel (gridDim.y = trial): one workgroup per 32-sample chunk and trial "
                         "(5 workgroups, never more per launch than CUs) for few trials, one workgroup per trial from ~160 trials on "
                         "(more trials through a CU per second; same bits); one all_gather of ser_by_word[300] per trial",
-                "roofline": training_roofline(st4, R4, 200, T2, True, 5),
+                "roofline": roof4,
                 "note": "training passes run one workgroup per 32-sample chunk and trial, gradients exchanged through a per-trial workspace "
                         "with one device-wide barrier per pass (DESIGN.md 5.6, 5.7)"})
     return out

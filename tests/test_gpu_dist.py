@@ -102,7 +102,7 @@ def test_bench_self_launch_four_ranks_with_configs():
     rehearsal of the 8-GPU run the driver launches (the GPU box admits at most 6 processes on the card at once, so 8 ranks
     cannot be rehearsed here)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    env.update(MVN_BENCH_BACKEND="gloo", MVN_BENCH_TRIALS_SELFSUP="6", MVN_BENCH_TRIALS_META="3")
+    env.update(MVN_BENCH_BACKEND="gloo", MVN_BENCH_TRIALS_SELFSUP="6", MVN_BENCH_TRIALS_META="3", MVN_BENCH_TRIALS_META_MORE="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
                         "--blocks", "512", "--sustained-seconds", "0.2"], env=env, capture_output=True, text=True, timeout=860)
     assert r.returncode == 0, r.stderr[-3000:]
