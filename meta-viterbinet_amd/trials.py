@@ -196,7 +196,8 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
     weights are re-initialised from ITS OWN stream (TrialDraws.init_weights) and its optimizer state reset.
     bank.optimizer_type 'RMSprop' / 'SGD' (deep_learning_setup, :163-175): the training kernels implement Adam, the reference's
     default; the other two optimizers run trial after trial through harness.eval_by_word on stock autograd -- same results as
-    calling it yourself, no batching.
+    calling it yourself, no batching.  So do detectors with another state count than 16 (the one-launch block step and its
+    R-word form serve 16 states): trial after trial through harness.eval_by_word, there on the run-time-n_states training kernels.
     cohorts > 1: the trials are split into that many groups that step ALTERNATELY on the same stream: while the GPU works
     through one group's training launches the host takes the decisions and fills the descriptors of the next (the host
     work of a step can only start after the step's sync).  Same launches per trial, same results."""
@@ -214,7 +215,7 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
         if ib[0].shape != ib[1].shape or ib[0].shape[0] != R or ib[0].shape[2] != rx.shape[2]:
             raise ValueError("initial_buffer = (tx_codewords, rx_words), each [W0, T] or [R, W0, T]")
         initial_buffer = ib
-    if bank.optimizer_type != "Adam":
+    if bank.optimizer_type != "Adam" or bank.n_states != 16:
         return _one_trial_at_a_time(bank, tx, rx, n_symbols, subframes_in_frame, draws, ser_by_word, record, initial_buffer,
                                     dict(self_supervised=self_supervised, self_supervised_iterations=self_supervised_iterations,
                                          ser_thresh=ser_thresh, online_meta=online_meta, meta_lr=meta_lr, MAML=MAML, window_size=window_size,
@@ -247,8 +248,9 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
 
 def _one_trial_at_a_time(bank, tx, rx, n_symbols, subframes_in_frame, draws, ser_by_word, record, initial_buffer, kw,
                          train_minibatch_size):
-    """The trials of a bank whose optimizer the training kernels do not implement (RMSprop, SGD), one after the other through
-    harness.eval_by_word (stock autograd); weights, saved weights, optimizer state and step counts go back into the bank."""
+    """The trials of a bank the lock-step engine does not serve -- an optimizer the training kernels do not implement (RMSprop,
+    SGD: stock autograd) or another state count than 16 (no R-word block step) -- one after the other through harness.eval_by_word;
+    weights, saved weights, optimizer state and step counts go back into the bank."""
     from .detectors import META_VNETDetector, VNETDetector
     from .harness import eval_by_word
     from .online import OnlineTrainer

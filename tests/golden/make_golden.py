@@ -456,7 +456,7 @@ def g11_meta_train_loop():
 
 
 # ----------------------------------------------------------------------------- G12, G13
-def _by_word_flow(out, tag, cls, kw, g7, blocks_frames=3):
+def _by_word_flow(out, tag, cls, kw, g7, blocks_frames=3, weights=None):
     """One run of the unmodified reference's evaluate() -> eval_by_word (trainer.py:267-354, :368-381) from the reference-trained
     weights of G7 (saved as the checkpoint load_weights reads), with every random draw it makes recorded in call order:
     torch.multinomial (select_batch, :542), torch.randint (j_hat, :337) and -- weights_init='random' -- the weights
@@ -477,7 +477,9 @@ def _by_word_flow(out, tag, cls, kw, g7, blocks_frames=3):
     tr = cls(**base)
     sd = tr.detector.state_dict()
     for i, k in enumerate(["net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias"]):
-        sd[k] = torch.tensor(g7[f"w{i}"])
+        sd[k] = torch.tensor(g7[f"w{i}"] if weights is None else weights[i])
+        if weights is not None:  # (another state count than G7's: the run's starting weights travel with it)
+            out[f"{tag}_w0_{i}"] = np.asarray(weights[i], np.float32)
     torch.save({"model_state_dict": sd, "optimizer_state_dict": {}, "loss": 0.0}, os.path.join(wdir, "snr_9_gamma_0.2.pt"))
     tx_msg, rx = tr.channel_dataset["val"].__getitem__(snr_list=[9], gamma=0.2)  # same seeds -> the words evaluate() will draw
     if not base["buffer_empty"]:
@@ -582,6 +584,28 @@ def g15_by_word_reference_defaults():
     save("g15_by_word_reference_defaults", **out)
 
 
+def g16_by_word_other_state_counts():
+    """eval_by_word with updates at other channel memories than 4: ViterbiNet with 8 states (memory 3) and 32 states (memory 5),
+    briefly trained by the reference's own trainer (train_vnet), then 50 blocks of the self-supervised and the meta-learning flow each,
+    recorded like G12 / G13 -- the run-time-n_states instantiations of the training kernels and the block step's separate launches."""
+    from python_code.trainers.META_VNET.metavnet_trainer import METAVNETTrainer
+
+    out = {}
+    meta = dict(self_supervised=True, self_supervised_iterations=6, online_meta=True, MAML=True, meta_lr=0.1, window_size=1,
+                meta_train_iterations=2, meta_j_num=4, meta_subframes=5, weights_init="last_frame")
+    selfsup = dict(self_supervised=True, self_supervised_iterations=8, online_meta=False)
+    for L in (3, 5):
+        import contextlib
+        import io
+
+        with contextlib.redirect_stdout(io.StringIO()):
+            w = export_weights(train_vnet(L, 10).detector)
+        # (the reference's fading taps exist for memory 4 only, channel_estimation.py: a static channel here)
+        _by_word_flow(out, f"L{L}_selfsup", VNETTrainer, dict(selfsup, memory_length=L, fading_in_channel=False), None, 2, weights=w)
+        _by_word_flow(out, f"L{L}_meta", METAVNETTrainer, dict(meta, memory_length=L, fading_in_channel=False), None, 2, weights=w)
+    save("g16_by_word_other_state_counts", **out)
+
+
 # ----------------------------------------------------------------------------- G14
 def g14_aggregated_evaluate():
     """Trainer.evaluate() in 'aggregated' mode (trainer.py:368-381 -> evaluate_at_point :254-265 -> gamma_eval :243-252 ->
@@ -681,14 +705,16 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g14":
         g14_aggregated_evaluate()
         g15_by_word_reference_defaults()
+        g16_by_word_other_state_counts()
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] in ("g12", "g13", "g15"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("g12", "g13", "g15", "g16"):
         import contextlib
         import io
 
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):  # (the reference prints every block)
-            {"g12": g12_by_word_with_updates, "g13": g13_by_word_switches, "g15": g15_by_word_reference_defaults}[sys.argv[1]]()
+            {"g12": g12_by_word_with_updates, "g13": g13_by_word_switches, "g15": g15_by_word_reference_defaults,
+             "g16": g16_by_word_other_state_counts}[sys.argv[1]]()
         print("\n".join(l for l in buf.getvalue().splitlines() if l.startswith(("g12", "wrote"))))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g10":

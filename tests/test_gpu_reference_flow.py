@@ -82,7 +82,8 @@ class RecordedDraws:
 
 
 # the harness arguments of every recorded flow beyond its iteration counts (tests/golden/make_golden.py: g12 / g13)
-FLOWS = {"selfsup": {}, "meta": dict(online_meta=True), "c2_selfsup": {}, "c4_meta": dict(online_meta=True), "fomaml": dict(online_meta=True, MAML=False),
+FLOWS = {"selfsup": {}, "meta": dict(online_meta=True), "c2_selfsup": {}, "c4_meta": dict(online_meta=True),
+         "L3_selfsup": {}, "L3_meta": dict(online_meta=True), "L5_selfsup": {}, "L5_meta": dict(online_meta=True), "fomaml": dict(online_meta=True, MAML=False),
          "window": dict(online_meta=True, window=True), "random": dict(online_meta=True, weights_init="random"),
          "metatrain": dict(online_meta=True, weights_init="meta_training"), "support2": dict(online_meta=True, window_size=2),
          "rmsprop": dict(optimizer_type="RMSprop"), "sgd": dict(optimizer_type="SGD", lr=0.05)}
@@ -104,6 +105,11 @@ def _flow_kwargs(g, g7, tag, dev):
     return kw, f, nsym, subframes  # f: what is left is the optimizer's (optimizer_type, lr)
 
 
+def _start_weights(g, g7, tag):
+    """the weights the reference's run started from: G7's at 16 states, the run's own (w0) at other state counts"""
+    return [g[f"{tag}_w0_{i}"] if f"{tag}_w0_{i}" in g.files else g7[f"w{i}"] for i in range(6)]
+
+
 def _recorded(g, tag, dev):
     return RecordedDraws(g[f"{tag}_multinomial"], g[f"{tag}_randint_high"], g[f"{tag}_randint"], dev,
                          g[f"{tag}_init_weights"] if f"{tag}_init_weights" in g.files else None)
@@ -114,15 +120,17 @@ def _run(g, g7, tag, dev, hip, lenient=False):
     rx = torch.tensor(g[f"{tag}_rx"], device=dev)
     kw, opt, nsym, subframes = _flow_kwargs(g, g7, tag, dev)
     T = rx.shape[1]
-    det = mvn.VNETDetector(16, {"train": T, "val": T}).to(dev)
+    w0 = _start_weights(g, g7, tag)
+    S = w0[5].shape[0]
+    det = mvn.VNETDetector(S, {"train": T, "val": T}).to(dev)
     with torch.no_grad():
-        for p, i in zip(det.parameters(), range(6)):
-            p.copy_(torch.as_tensor(g7[f"w{i}"]))
-    tr = mvn.OnlineTrainer(det, 4, use_kernel=hip, **opt)
+        for p, a in zip(det.parameters(), w0):
+            p.copy_(torch.as_tensor(a))
+    tr = mvn.OnlineTrainer(det, int(np.log2(S)), use_kernel=hip, **opt)
     draws = _recorded(g, tag, dev)
     draws.lenient = lenient
     if kw.get("online_meta"):
-        kw["meta_detector"] = mvn.META_VNETDetector(16, {"train": T, "val": T})
+        kw["meta_detector"] = mvn.META_VNETDetector(S, {"train": T, "val": T})
     last = {}
 
     def observer(seen):  # the saved weights (the reference's saved_detector, trainer.py:275/:343) as the last block leaves them
@@ -182,6 +190,43 @@ def test_reference_by_word_switches(golden, dev, tag, hip):
         msg += f"; saved weights end {worst_s:.2e} from the reference's"
         assert worst_s <= 5e-5, msg
     print(msg)
+
+
+G16 = ["L3_selfsup", "L3_meta", "L5_selfsup", "L5_meta"]
+
+
+@pytest.mark.parametrize("tag", G16)
+@pytest.mark.parametrize("route", ["hip_kernels", "torch_autograd", "batched_trials"])
+def test_reference_by_word_flow_other_state_counts(golden, dev, tag, route):
+    """Golden G16: the self-supervised and the meta-learning flow at 8 and 32 states (channel memory 3 and 5), recorded runs of the
+    unmodified reference from weights its own trainer produced: the run-time-n_states instantiations of the training kernels
+    (online_train / maml_train _kernel<0, ...>, their chunked forms) and the block step as separate launches (the one-launch step
+    serves 16 states).  ser_by_word identical on all 50 blocks, final weights within 5e-5 of the reference's, on every route."""
+    from meta_viterbinet_amd.trials import TrialBank, eval_by_word_batched
+
+    g, g7 = golden("g16_by_word_other_state_counts"), golden("g7_by_word")
+    ref, w0 = g[f"{tag}_ser_by_word"], _start_weights(g, g7, tag)
+    S = w0[5].shape[0]
+    if route == "batched_trials":
+        R = 3
+        kw, opt, nsym, subframes = _flow_kwargs(g, g7, tag, dev)
+        tx = torch.tensor(g[f"{tag}_tx"], device=dev).float().unsqueeze(0).repeat(R, 1, 1)
+        rx = torch.tensor(g[f"{tag}_rx"], device=dev).unsqueeze(0).repeat(R, 1, 1)
+        bank = TrialBank([w0] * R, S, int(np.log2(S)), dev)
+        draws = [RecordedTableDraws(g, tag, kw["self_supervised_iterations"], subframes, dev) for _ in range(R)]
+        ser_all = eval_by_word_batched(bank, tx, rx, nsym, subframes, draws, **kw)
+        ser, w = ser_all[0], [t.cpu().numpy() for t in bank.weights(0)]
+        assert np.array_equal(ser_all[1], ser) and np.array_equal(ser_all[2], ser) and torch.equal(bank.theta[0], bank.theta[2])
+        assert all(d.used_up() for d in draws)
+    else:
+        ser, draws, w, _ = _run(g, g7, tag, dev, route == "hip_kernels")
+        assert draws.used_up(), (draws.m_at, len(draws.multinomial), draws.r_at, len(draws.randint))
+    assert ser.shape == ref.shape == (50,)
+    assert np.array_equal(ser, ref), (np.flatnonzero(ser != ref), ser[ser != ref], ref[ser != ref])
+    moved = max(float(np.abs(g[f"{tag}_w1_{i}"] - w0[i]).max()) for i in range(6))
+    worst = max(float(np.abs(w[i] - g[f"{tag}_w1_{i}"]).max()) for i in range(6))
+    print(f"g16 {tag} ({S} states) {route}: ser identical on 50 blocks; weights moved {moved:.4f}, end {worst:.2e} from the reference's")
+    assert moved > 0.005 and worst <= 5e-5
 
 
 # blocks of G15 over which every route must reproduce the reference's ser_by_word exactly (measured first differences: c2 block 34
