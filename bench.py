@@ -668,9 +668,14 @@ def main():
         out["configs"] = configs
         if sustained is not None:
             sustained["ratio_to_value"] = sustained["symbols_per_s"] * world / out["value"]  # per-GPU sustained rate x N vs the timed region
-        if not args.no_cpu_baseline:  # rank 0's host cores, at every N (the other ranks wait in the barrier below)
+        if args.no_cpu_baseline:
+            pass
+        elif world == 1:  # rank 0's host cores, at N = 1 only: at N > 1 the other ranks would sit in the barrier below for ~30 s
             out["cpu_baseline"] = cpu_baseline([w.cpu().numpy() for w in weights], 3450002)
             out["cpu_baseline_torch_path"] = cpu_baseline_torch_path([w.cpu().numpy() for w in weights], 3450002)
+        else:
+            out["cpu_baseline"] = {"value": None, "unit": "symbols/s", "cores": None, "kind": "port",
+                                   "sample": "timed at N=1 only (the other ranks would wait for it); see the N=1 line"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

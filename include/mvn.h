@@ -195,8 +195,10 @@ size_t mvn_vnet_train_workspace_bytes(int32_t n_states);
  * that cannot become resident must not hang the device).  If a wait is abandoned the weights come back as NaN AND *status is
  * set to 1 (the caller zeroes it; it is never written otherwise): check it wherever the host next synchronises -- the
  * counterpart of the reference's NaN-loss guard, trainer.py:496-498.  Concurrent launches of this form (different streams,
- * different workspaces) are safe while their combined workgroups (one per 32-sample chunk) fit the device's CUs; to run many
- * words at once use the *_trials_* entry points below, which put them into ONE launch. */
+ * different workspaces) are safe while their combined workgroups (one per 32-sample chunk) fit the device's CUs -- words of up
+ * to 256 symbols are placed on ONE XCD each (their gradient exchange stays in its L2), the XCD taken in rotation from launch to
+ * launch, so that bound is then 32 CUs per XCD: at least 4 such launches per XCD, 32 on the device; to run many words at once
+ * use the *_trials_* entry points below, which put them into ONE launch. */
 int mvn_vnet_online_train_ws_f32(const float *y, const int32_t *labels, int32_t T, const int32_t *batch_idx, int32_t M,
                                  int32_t n_iter, float *W1, float *b1, float *W2, float *b2, float *W3, float *b3,
                                  float *adam_m, float *adam_v, int64_t step0, float lr, float beta1, float beta2, float eps,

@@ -824,12 +824,22 @@ size_t trial_workspace_floats(int S, int groups) {
 // trial 9.4 -> 8.8 us, a second-order step 38 -> 36 us; profiles/r04_time_groups_xcd_ab.txt).  The units hold a few trials less
 // per launch than CUs / groups (48 instead of 51 at 5 workgroups per trial): the (groups, trials) grid, whose workgroups of a
 // trial land on different XCDs, stays where the XCD-aware one would need more launches.  MVN_TRAIN_XCD=0: never (A/B; same bits).
-bool xcd_grid(int groups, int cus, int R) {
+// The single-trial entry points (`many` false) may have launches in flight on several streams.  Each of them would put its G
+// workgroups on the XCD the dispatcher starts a grid on, and two launches that each hold a part of that XCD's 32 CUs would wait
+// for each other until the spin limit: their slot within the unit is therefore rotated from launch to launch (xcd_first), and
+// above 8 workgroups per trial (T > 256) they keep the (groups, trials) grid, whose workgroups spread over all 256 CUs -- an XCD
+// then holds at least 4 single-trial launches, 32 over the device, like the classic grid at that size.  (For either grid the
+// chunked launches in flight together must fit the device's CUs; include/mvn.h.)
+constexpr int kXcdSingleMaxGroups = 8;
+std::atomic<unsigned> g_xcd_rotation{0};
+bool xcd_grid(int groups, int cus, int R, bool many = true) {
     if (sw(SW_TRAIN_XCD) == '0' || groups < 2 || 8 * groups > cus) return false;
+    if (!many && groups > kXcdSingleMaxGroups) return false;
     const int fit_x = 8 * (cus / (8 * groups)), fit_c = cus / groups;
     return (R + fit_x - 1) / fit_x <= (R + fit_c - 1) / fit_c;
 }
 int group_trials_fit(int groups, int cus, int R) { return xcd_grid(groups, cus, R) ? 8 * (cus / (8 * groups)) : cus / groups; }
+int next_xcd_slot(bool xcd, bool many) { return xcd && !many ? (int)(g_xcd_rotation.fetch_add(1, std::memory_order_relaxed) & 7u) : 0; }
 unsigned group_grid_blocks(int groups, int trials) { return (unsigned)(8 * groups * ((trials + 7) / 8)); }
 
 // R trials, at most `fit` per launch (workgroups <= CUs): as few launches as possible, of equal size (29 trials with room for
@@ -935,7 +945,7 @@ int launch_online_train(const mvn_train_trial_t &one, const mvn_train_trial_t *m
     }
     // one workgroup per chunk and trial, never more workgroups in a launch than the device has CUs (all resident at once)
     const size_t ws_floats_one = train_groups_workspace_bytes(S, groups) / sizeof(float);
-    const bool xcd = xcd_grid(groups, cus, R);
+    const bool xcd = xcd_grid(groups, cus, R, many != nullptr);
     const int per_launch = many ? trials_per_launch(R, group_trials_fit(groups, cus, R)) : 1;
     for (int r0 = 0; r0 < R; r0 += per_launch) {
         const int nr = std::min(per_launch, R - r0);
@@ -943,7 +953,7 @@ int launch_online_train(const mvn_train_trial_t &one, const mvn_train_trial_t *m
         hipError_t e = clear_group_syncs(wsr, stride, nr, st);
         if (e != hipSuccess) return (int)e;
         const GroupLaunch gl = {wsr, (long long)stride, (unsigned)((many ? stride : ws_floats_one) * sizeof(float)), group_spin_limit(), group_phantoms(),
-                                xcd ? groups : 0, nr};
+                                xcd ? groups : 0, nr, next_xcd_slot(xcd, many != nullptr)};
         const dim3 grid = xcd ? dim3(group_grid_blocks(groups, nr)) : dim3((unsigned)groups, (unsigned)nr);
         const int rc = dispatch_states(S, many != nullptr, [&](auto sc) -> int {
             constexpr int SC = decltype(sc)::value;
@@ -988,7 +998,7 @@ int launch_maml_train(const mvn_train_trial_t &one, const mvn_train_trial_t *man
         });
     }
     const size_t ws_floats_one = maml_groups_workspace_bytes(S, groups) / sizeof(float);
-    const bool xcd = xcd_grid(groups, cus, R);
+    const bool xcd = xcd_grid(groups, cus, R, many != nullptr);
     const int per_launch = many ? trials_per_launch(R, group_trials_fit(groups, cus, R)) : 1;
     for (int r0 = 0; r0 < R; r0 += per_launch) {
         const int nr = std::min(per_launch, R - r0);
@@ -996,7 +1006,7 @@ int launch_maml_train(const mvn_train_trial_t &one, const mvn_train_trial_t *man
         hipError_t e = clear_group_syncs(wsr, stride, nr, st);
         if (e != hipSuccess) return (int)e;
         const GroupLaunch gl = {wsr, (long long)stride, (unsigned)((many ? stride : ws_floats_one) * sizeof(float)), group_spin_limit(), group_phantoms(),
-                                xcd ? groups : 0, nr};
+                                xcd ? groups : 0, nr, next_xcd_slot(xcd, many != nullptr)};
         const dim3 grid = xcd ? dim3(group_grid_blocks(groups, nr)) : dim3((unsigned)groups, (unsigned)nr);
         const int rc = dispatch_states(S, many != nullptr, [&](auto sc) -> int {
             constexpr int SC = decltype(sc)::value;
@@ -1326,7 +1336,7 @@ int mvn_vnet_train_kernel_name(int32_t kind, int32_t R, int32_t T, int32_t M_or_
     } else {
         const int per_launch = many ? trials_per_launch(n_trials, group_trials_fit(groups, current_device_cus(), n_trials)) : 1;
         const int launches = (n_trials + per_launch - 1) / per_launch;
-        const char *place = xcd_grid(groups, current_device_cus(), n_trials) ? " one XCD per trial" : "";
+        const char *place = xcd_grid(groups, current_device_cus(), n_trials, many) ? " one XCD per trial" : "";
         if (launches > 1)
             snprintf(name, (size_t)name_len, "%s_groups_kernel<%d, %s> %dx%d in %d launches%s", base, sc, many ? "true" : "false", groups,
                      per_launch, launches, place);

@@ -471,6 +471,40 @@ def test_two_training_launches_in_flight(golden, dev):
     assert all(bool(torch.isfinite(a).all()) for a in serial)
 
 
+@pytest.mark.parametrize("T,n_streams", [(136, 8), (544, 2), (544, 9)])
+def test_single_trial_launches_on_many_streams_do_not_starve_one_xcd(golden, dev, T, n_streams):
+    """Single-trial chunked training calls in flight on several streams: 8 x 5 workgroups (T = 136) would not fit the ONE
+    XCD (32 CUs) an XCD-aware grid starts on if every launch took the same slot; two (or nine) launches of 17 workgroups
+    (T = 544) could each hold a part of it and wait for each other until the spin limit.  The launcher rotates the slot from
+    launch to launch and keeps the (groups, trials) grid above 8 workgroups per trial: every call returns finite weights with
+    status 0, identical to the serial run."""
+    g7 = golden("g7_by_word")
+    w = [g7[f"w{i}"] for i in range(6)]
+    gen = torch.Generator(device=dev).manual_seed(T)
+    y = torch.randn(n_streams, T, generator=gen, device=dev)
+    tx = torch.randint(0, 2, (n_streams, T), generator=gen, device=dev).float()
+
+    def run(concurrent):
+        dets = [_vnet_with(w, T, dev) for _ in range(n_streams)]
+        trs = [mvn.OnlineTrainer(d, 4) for d in dets]
+        torch.cuda.synchronize()
+        cur = torch.cuda.current_stream(dev)
+        streams = [torch.cuda.Stream(dev) if concurrent else cur for _ in range(n_streams)]
+        for rep in range(2):
+            for k in range(n_streams):
+                with torch.cuda.stream(streams[k]):
+                    trs[k].online_training(tx[k:k + 1], y[k:k + 1], iterations=120, full_word=True)
+        torch.cuda.synchronize()
+        for t in trs:
+            t.check_status()
+        return [p.detach().clone() for d in dets for p in d.parameters()]
+
+    serial, overlapped = run(False), run(True)
+    assert all(bool(torch.isfinite(a).all()) for a in overlapped)
+    for a, b in zip(serial, overlapped):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("form", sorted(FORMS))
 @pytest.mark.parametrize("S,T", [(4, 100), (32, 136), (8, 40)])
 def test_trial_entry_points_for_other_state_counts(dev, monkeypatch, S, T, form):
