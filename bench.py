@@ -301,8 +301,14 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
         # the form the library itself picks for this many trials (mvn_vnet_train_kernel_name: chunked passes finish a trial
         # soonest, one workgroup per trial gets the most trials through a CU per second)
         ws_b = int(lib.mvn_vnet_train_trials_workspace_bytes(16, T2, 1, trials))
-        form = kernel_name(lib.mvn_vnet_train_kernel_name, 2 if maml else 0, trials, T2, 1 if maml else (0 if samples == T2 else samples), 16, ws_b)
+        # the launcher decides per call from the trials that are ACTIVE in it: priced at the mean active count per block step
+        act_online = max(1, min(trials, round(stats["trained"] / N)))
+        act_meta = max(1, min(trials, round(stats["meta"] / max(1, N // 5)))) if maml else 0
+        form_online = kernel_name(lib.mvn_vnet_train_kernel_name, 0, act_online, T2, 0 if samples == T2 else samples, 16, ws_b)
+        form_maml = kernel_name(lib.mvn_vnet_train_kernel_name, 2, act_meta, T2, 1, 16, ws_b) if maml else None
+        form = form_maml if maml else form_online
         groups, per_launch = (int(v) for v in form.split("> ")[1].split(" ")[0].split("x"))
+        groups_online = int(form_online.split("> ")[1].split(" ")[0].split("x")[0])
         # the same flow priced by the MFMA instructions its training launches EXECUTE (SQ_INSTS_MFMA per iteration and trial from
         # the committed PMC passes of tools/prof_train_kernels.py, profiles/train_pmc.json; x 2048 FLOP), and what those passes say
         # the dominant training kernel waits for while it runs
@@ -313,7 +319,7 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
                 pmc_src = f"profiles/train_pmc.json: taken on another build of csrc/ ({pmc.get('csrc_sha16')}), not reported"
             else:
                 c = pmc["cases"]
-                online_case = c["online_minibatch" if samples != T2 else ("online_full_word" if groups == 1 else "online_full_word_chunked")]
+                online_case = c["online_minibatch" if samples != T2 else ("online_full_word" if groups_online == 1 else "online_full_word_chunked")]
                 maml_case = c["maml_second_order" if groups == 1 else "maml_second_order_chunked"]
                 mfma = online_case["mfma_per_iteration"] * online_steps + maml_case["mfma_per_iteration"] * maml_steps
                 executed = mfma * 2048.0 / (stats["ms"] * 1e-3) / 1e12
@@ -326,7 +332,10 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
         return {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                 "achieved_executed_mfma": executed, "frac_executed_mfma": None if executed is None else executed / PEAK_F32_MFMA_TFLOPS,
                 "dominant_kernel_while_running": in_kernel, "pmc_source": pmc_src,
-                "cu_occupancy": min(1.0, per_launch * groups / n_cu.value), "training_kernel": form, "workgroups_per_trial": groups,
+                "cu_occupancy": min(1.0, per_launch * groups / n_cu.value), "training_kernel": form, "online_training_kernel": form_online,
+                "forms_priced_at": {"active_trials_per_online_call": act_online, "active_trials_per_meta_call": act_meta,
+                                    "note": "the launcher picks the form per call from the trials active in it; mean counts of this run"},
+                "workgroups_per_trial": groups,
                 "trials_per_launch": per_launch,
                 "adam_steps": stats["adam_steps"], "algorithmic_flop": flop}
 

@@ -54,7 +54,7 @@ typedef void *mvn_stream_t; /* hipStream_t */
 
 #define MVN_E_BARRIER (-7)   /* (status words only) a training launch abandoned its device-wide barrier */
 
-#define MVN_ABI_VERSION 5 /* 5: + mvn_vnet_train_kernel_name, mvn_va_byword_step_f32; 4: + trial-batched training / by-word step, status words; 3: training with a workspace; 2: kernel-name queries */
+#define MVN_ABI_VERSION 6 /* 6: workspace arguments on mvn_vnet_decode_count_f32 (the dealt 16-state kernel's hand-off lines); 5: + mvn_vnet_train_kernel_name, mvn_va_byword_step_f32; 4: + trial-batched training / by-word step, status words; 3: training with a workspace; 2: kernel-name queries */
 
 /* ABI version of the loaded library (== MVN_ABI_VERSION). */
 int mvn_version(void);
@@ -117,19 +117,25 @@ int mvn_vnet_logits_f32(const float *y, const float *W1, const float *b1, const 
                         const float *b2, const float *W3, const float *b3, float *logits,
                         int64_t N, int32_t S, mvn_stream_t stream);
 
-/* Bytes of scratch mvn_vnet_decode_f32 wants to run (B,T,S) in one pass; any size that
- * holds at least one block (T*S*4 bytes) is accepted and processed in slices.  0 when the
- * shape is served by a fused kernel (the likelihood MLP runs inside the trellis sweep, the
- * logits never reach HBM), which needs none: S = 4 ... 64 by default, S = 128 and 256 with
- * MVN_FUSED_IP=1 in the environment (there the two-kernel route -- MLP -> logits in scratch ->
- * sweep -- is the faster one and the default; S = 2 and MVN_UNFUSED=1 always take it). */
+/* Bytes of scratch mvn_vnet_decode_f32 / mvn_vnet_decode_count_f32 want to run (B,T,S) in one pass.
+ *  - Two-kernel route (S = 2, S = 128 / 256 by default, MVN_UNFUSED=1): the logits of the batch; any size that holds
+ *    at least one block (T*S*4 bytes) is accepted and processed in slices.
+ *  - S = 16, more than 768 blocks: at most 100 KB of hand-off lines for the dealt kernel (vnet16_dealt_kernel: the batch's
+ *    32-symbol units shared evenly by 3 workgroups per CU, a block's 16 path metrics handed from wave to wave); 128-byte
+ *    aligned, contents irrelevant before and after, not to be shared by calls that may run concurrently.  Without it
+ *    (NULL / smaller / unaligned) the one-wave-per-block kernel runs: same bits, 4 % slower at 10 000 x 1000 and up to 2 x at
+ *    a thousand blocks.  Word 0 of the workspace is a status word: non-zero after the call only if a hand-off wait was
+ *    abandoned (the lower-numbered workgroup it waits for did not publish within seconds; the affected decisions are NaN).
+ *  - 0 when the shape is served by a fused kernel that needs none (S = 4 ... 64 by default, S = 128 and 256 with
+ *    MVN_FUSED_IP=1; S = 16 up to 768 blocks of up to 1024 symbols: the cooperative kernel). */
 size_t mvn_vnet_workspace_bytes(int64_t B, int32_t T, int32_t S);
 
 /*
  * VNETDetector.forward(y,'val'), python_code/detectors/VNET/vnet_detector.py:35-61, and
  * META_VNETDetector.forward(y,'val',var), meta_vnet_detector.py:24-45 (var = the six arrays).
  *   y [B, y_ld>=T]; dec [B, dec_ld>=T]; logits_out [B,T,S] or NULL; final_metric [B,S] or NULL;
- *   workspace: device scratch (may be NULL when logits_out is given or a fused kernel runs: mvn_vnet_workspace_bytes == 0).
+ *   workspace: device scratch of mvn_vnet_workspace_bytes(B, T, S) bytes (may be NULL when that is 0 or -- two-kernel route --
+ *   logits_out is given; S = 16: optional, see there).
  *   With logits_out the logits are materialised there (S != 16: by the two-kernel route).
  */
 int mvn_vnet_decode_f32(const float *y, int64_t y_ld, const float *W1, const float *b1,
@@ -145,14 +151,15 @@ int mvn_vnet_decode_f32(const float *y, int64_t y_ld, const float *W1, const flo
  *   tx [B, tx_ld>=K] fp32 {0,1}: transmitted words; the first K <= T columns are compared;
  *   row_mask: uint8[B] or NULL; rows with mask 0 (pilots, trainer.py:100-102) are decoded but not counted;
  *   counters: device int64[4], += {bit_errors, bits, frame_errors, frames};
- *   dec: optional [B, dec_ld>=T] decisions output (NULL = do not store).
+ *   dec: optional [B, dec_ld>=T] decisions output (NULL = do not store);
+ *   workspace / workspace_bytes: as for mvn_vnet_decode_f32 (mvn_vnet_workspace_bytes(B, T, 16); may be NULL / 0).
  * Returns MVN_E_STATES for S != 16 (use mvn_vnet_decode_f32 + mvn_count_errors there).
  */
 int mvn_vnet_decode_count_f32(const float *y, int64_t y_ld, const float *W1, const float *b1,
                               const float *W2, const float *b2, const float *W3, const float *b3,
                               const float *tx, int64_t tx_ld, int32_t K, const uint8_t *row_mask,
-                              int64_t *counters, float *dec, int64_t dec_ld, int64_t B, int32_t T,
-                              int32_t S, mvn_stream_t stream);
+                              int64_t *counters, float *dec, int64_t dec_ld, void *workspace,
+                              size_t workspace_bytes, int64_t B, int32_t T, int32_t S, mvn_stream_t stream);
 
 /*
  * calculate_error_rates, python_code/utils/metrics.py:7-17, as integer counters so that

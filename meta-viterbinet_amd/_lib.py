@@ -9,7 +9,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVN_LIB_PATH", os.path.join(_PKG, "libmvn_hip.so"))  # override: A/B builds
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -32,7 +32,7 @@ SIGNATURES = {
     "mvn_vnet_decode_f32": (ctypes.c_int, [_vp, _i64] + [_vp] * 6 + [_vp, _i64, _vp, _vp, _vp, ctypes.c_size_t,
                                                                    _i64, _i32, _i32, _vp]),
     "mvn_vnet_decode_count_f32": (ctypes.c_int, [_vp, _i64] + [_vp] * 6 + [_vp, _i64, _i32, _vp, _vp, _vp, _i64,
-                                                 _i64, _i32, _i32, _vp]),
+                                                 _vp, ctypes.c_size_t, _i64, _i32, _i32, _vp]),
     "mvn_vnet_online_train_f32": (ctypes.c_int, [_vp, _vp, _i32, _vp, _i32, _i32] + [_vp] * 8 +
                                   [_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _i32, _vp]),
     "mvn_vnet_train_workspace_bytes": (ctypes.c_size_t, [_i32]),

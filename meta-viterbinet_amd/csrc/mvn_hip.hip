@@ -22,6 +22,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <math.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -415,8 +417,11 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
     return (int)hipGetLastError();
 }
 
+int current_device_cus();  // CUs of the current device, cached per device (defined below the kernels)
+
 #include "vnet16_fused.inc"
 #include "vnet16_fusedn.inc"
+#include "vnet16_dealt.inc"
 #include "vnet16_coop.inc"
 #include "va16_tile.inc"
 #include "sweep16_rows.inc"
@@ -550,10 +555,10 @@ __global__ __launch_bounds__(256) void isi_awgn_kernel(const float *__restrict__
 // They are read from the environment ONCE per process -- the by-word evaluation calls into the library every few
 // microseconds -- and again when the caller asks (mvn_reload_switches: the test-suite flips them between calls).
 enum Switch { SW_UNFUSED, SW_COOP, SW_FUSEDN, SW_GENERIC_SWEEP, SW_VA256, SW_VA_INPLACE, SW_VA16, SW_SWEEP_INPLACE, SW_SWEEP16,
-              SW_TRAIN_GROUPS, SW_TRAIN_PAIR, SW_FUSED_IP, SW_TRAIN_XCD, SW_COUNT };
+              SW_TRAIN_GROUPS, SW_TRAIN_PAIR, SW_FUSED_IP, SW_TRAIN_XCD, SW_DEALT, SW_COUNT };
 const char *const kSwitchNames[SW_COUNT] = {"MVN_UNFUSED", "MVN_COOP", "MVN_FUSEDN", "MVN_GENERIC_SWEEP", "MVN_VA256",
                                             "MVN_VA_INPLACE", "MVN_VA16", "MVN_SWEEP_INPLACE", "MVN_SWEEP16", "MVN_TRAIN_GROUPS",
-                                            "MVN_TRAIN_PAIR", "MVN_FUSED_IP", "MVN_TRAIN_XCD"};
+                                            "MVN_TRAIN_PAIR", "MVN_FUSED_IP", "MVN_TRAIN_XCD", "MVN_DEALT"};
 // The library may be called from several host threads: the table is atomics (a reload while another thread launches gives that
 // launch either the old or the new value of a switch, never a torn one), filled under a mutex.
 std::atomic<char> g_switch[SW_COUNT];
@@ -649,10 +654,70 @@ __global__ __launch_bounds__(1024) void count_totals_kernel(const unsigned char 
     }
 }
 
+// The dealt form of the fused kernel (vnet16_dealt.inc): every batch the cooperative kernel does not take, when the caller gave
+// the hand-off workspace (mvn_vnet_workspace_bytes) -- units of 32 symbols shared evenly by 3 workgroups per CU instead of whole
+// blocks per wave.  MVN_DEALT=0: never (the one-wave-per-block kernel: A/B runs, cross-checks); MVN_FUSEDN=4 implies that too.
+#ifdef MVN_TEST_HOOKS
+std::atomic<int> g_dealt_skip_ring{-1};        // the tests' build: this group never publishes its cross-group hand-off ...
+std::atomic<unsigned> g_dealt_spin_limit{kDealtSpinLimit};  // ... and the wait for it gives up after this many polls
+inline int dealt_skip_ring() { return g_dealt_skip_ring.load(std::memory_order_relaxed); }
+inline unsigned dealt_spin_limit() { return g_dealt_spin_limit.load(std::memory_order_relaxed); }
+#else
+inline int dealt_skip_ring() { return -1; }
+inline unsigned dealt_spin_limit() { return kDealtSpinLimit; }
+#endif
+// A fresh non-zero 64-bit number per launch (splitmix64 of a process-wide counter that starts at a value drawn from the clock and
+// the address space): the dealt kernel's hand-off flags are "set" when they hold it, so stale flags of earlier launches -- or
+// whatever else the caller's workspace held -- never look set (2^-64 per flag and launch).
+unsigned long long dealt_nonce() {
+    static std::atomic<unsigned long long> counter{0};
+    unsigned long long c = counter.load(std::memory_order_relaxed);
+    if (c == 0) {
+        timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        unsigned long long seed = ((unsigned long long)ts.tv_sec << 32) ^ (unsigned long long)ts.tv_nsec ^ reinterpret_cast<uintptr_t>(&counter) ^
+                                  ((unsigned long long)getpid() << 48);
+        if (seed == 0) seed = 1;
+        counter.compare_exchange_strong(c, seed, std::memory_order_relaxed);  // (one of the racing first callers wins)
+    }
+    unsigned long long z = counter.fetch_add(0x9E3779B97F4A7C15ull, std::memory_order_relaxed) + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z ? z : 1;
+}
+// Workgroups ("groups" of 8 waves, 3 per CU) and ring size of a dealt launch.  A ring -- `ring` consecutive waves of a group --
+// owns one contiguous range of the launch's units, which must hold at least one block: the more blocks, the smaller the rings
+// (8 x groups blocks: every wave a ring of its own, the path metrics stay in its registers except at the two ends of its range;
+// fewer: rings of 2, 4, 8 waves that hand the metrics round through LDS).  groups = 0: the shape is not dealt.
+struct DealtPlan {
+    int groups, ring;
+    int rings() const { return groups * (kDealtWaves / ring); }
+};
+DealtPlan dealt_plan(int64_t B, int T) {
+    DealtPlan p = {0, kDealtWaves};
+    if (sw(SW_DEALT) == '0' || fusedn_tiles() != 2 || coop_selected(B, T)) return p;
+    const int64_t units = ((int64_t)T + kDealtUnit - 1) / kDealtUnit;
+    if (B < 1 || B * units >= ((int64_t)1 << 31)) return p;
+    const int cus = current_device_cus();
+    const int64_t slots = 3 * (int64_t)(cus > 0 ? cus : 256);  // 3 workgroups of 8 waves per CU (80 VGPRs, 36 KB of LDS each)
+    p.groups = (int)(B < slots ? B : slots);
+    const char e = sw(SW_DEALT);  // MVN_DEALT=8|4|2 pins the ring size (A/B runs, tests); a ring never gets less than a block
+    int want = (e == '8' || e == '4' || e == '2') ? e - '0' : 1;
+    while (want < kDealtWaves && (int64_t)p.groups * (kDealtWaves / want) > B) want *= 2;
+    p.ring = want;
+    return p;
+}
+size_t dealt_workspace_bytes_for(int64_t B, int T) {
+    const DealtPlan p = dealt_plan(B, T);
+    return p.groups ? dealt_workspace_bytes(p.rings()) : 0;
+}
+
 int launch_vnet16_fused(const float *y, int64_t y_ld, const float *W1, const float *b1, const float *W2, const float *b2,
                         const float *W3, const float *b3, float *dec, int64_t dec_ld, float *logits_out,
                         float *final_metric, int64_t B, int T, const float *tx, int64_t tx_ld, int K,
-                        const unsigned char *row_mask, unsigned long long *counters, hipStream_t st) {
+                        const unsigned char *row_mask, unsigned long long *counters, hipStream_t st, void *workspace = nullptr,
+                        size_t workspace_bytes = 0) {
     if (coop_selected(B, T)) {  // small batch: a 16-wave workgroup per block (MLP tiles in parallel, one sweeping wave)
         const size_t dyn = (size_t)((T + 15) / 16) * 1024;
         const void *fn = logits_out ? (const void *)vnet16_coop_kernel<true> : (const void *)vnet16_coop_kernel<false>;
@@ -663,6 +728,20 @@ int launch_vnet16_fused(const float *y, int64_t y_ld, const float *W1, const flo
         else
             hipLaunchKernelGGL((vnet16_coop_kernel<false>), dim3((unsigned)B), dim3(64 * kCoopWaves), dyn, st, y, y_ld, W1, b1, W2, b2, W3,
                                b3, dec, dec_ld, logits_out, final_metric, B, T, tx, tx_ld, K, row_mask, counters);
+        if (tx) hipLaunchKernelGGL(count_totals_kernel, dim3(1), dim3(1024), 0, st, row_mask, B, K, counters);
+        return (int)hipGetLastError();
+    }
+    if (const DealtPlan dp = dealt_plan(B, T); dp.groups && workspace && workspace_bytes >= dealt_workspace_bytes(dp.rings()) &&
+                                               !(reinterpret_cast<uintptr_t>(workspace) & 127)) {
+        const unsigned long long nonce = dealt_nonce();  // what a SET hand-off flag holds in this launch: nothing to clear
+        if (logits_out)
+            hipLaunchKernelGGL((vnet16_dealt_kernel<true>), dim3((unsigned)dp.groups), dim3(64 * kDealtWaves), 0, st, y, y_ld, W1, b1, W2, b2,
+                               W3, b3, dec, dec_ld, logits_out, final_metric, (int)B, T, tx, tx_ld, K, row_mask, counters, (float *)workspace,
+                               dp.groups, dp.ring, dealt_spin_limit(), dealt_skip_ring(), nonce);
+        else
+            hipLaunchKernelGGL((vnet16_dealt_kernel<false>), dim3((unsigned)dp.groups), dim3(64 * kDealtWaves), 0, st, y, y_ld, W1, b1, W2, b2,
+                               W3, b3, dec, dec_ld, logits_out, final_metric, (int)B, T, tx, tx_ld, K, row_mask, counters, (float *)workspace,
+                               dp.groups, dp.ring, dealt_spin_limit(), dealt_skip_ring(), nonce);
         if (tx) hipLaunchKernelGGL(count_totals_kernel, dim3(1), dim3(1024), 0, st, row_mask, B, K, counters);
         return (int)hipGetLastError();
     }
@@ -1116,6 +1195,8 @@ int mvn_vnet_decode_kernel_name(int64_t B, int32_t T, int32_t S, int32_t want_lo
     if (S == 16 && !unfused_forced()) {
         if (coop_selected(B, T))
             snprintf(name, (size_t)name_len, "vnet16_coop_kernel<%s>", want_logits ? "true" : "false");
+        else if (const DealtPlan dp = dealt_plan(B, T); dp.groups)  // (given the workspace mvn_vnet_workspace_bytes asks for; without it the kernel below)
+            snprintf(name, (size_t)name_len, "vnet16_dealt_kernel<%s> rings of %d", want_logits ? "true" : "false", dp.ring);
         else
             snprintf(name, (size_t)name_len, "vnet16_fusedn_kernel<%s, %d>", want_logits ? "true" : "false", fusedn_tiles());
     } else if (!want_logits && fused_ip_selected(S)) {  // one kernel: the MLP fused into the in-place sweep
@@ -1153,7 +1234,8 @@ int mvn_vnet_logits_f32(const float *y, const float *W1, const float *b1, const 
 
 size_t mvn_vnet_workspace_bytes(int64_t B, int32_t T, int32_t S) {
     if (B <= 0 || T <= 0 || S <= 0) return 0;
-    if ((S == 16 && !unfused_forced()) || fused_ip_selected(S)) return 0;  // the fused kernels keep the logits on chip
+    if (S == 16 && !unfused_forced()) return dealt_workspace_bytes_for(B, T);  // hand-off lines of the dealt kernel (<= 100 KB), or 0
+    if (fused_ip_selected(S)) return 0;  // the fused kernels keep the logits on chip
     return (size_t)B * (size_t)T * (size_t)S * sizeof(float);
 }
 
@@ -1168,7 +1250,7 @@ int mvn_vnet_decode_f32(const float *y, int64_t y_ld, const float *W1, const flo
     hipStream_t st = (hipStream_t)stream;
     if (S == 16 && !unfused_forced())  // fused single-kernel path: no scratch, 8 B/symbol of HBM traffic
         return launch_vnet16_fused(y, y_ld, W1, b1, W2, b2, W3, b3, dec, dec_ld, logits_out, final_metric, B, T, nullptr, 0,
-                                   0, nullptr, nullptr, st);
+                                   0, nullptr, nullptr, st, workspace, workspace_bytes);
     if (!logits_out && fused_ip_selected(S))  // other state counts: the MLP fused into the in-place sweep
         return launch_vnet_fused_ip(y, y_ld, W1, b1, W2, b2, W3, b3, dec, dec_ld, final_metric, B, T, S, st);
     const size_t per_block = (size_t)T * (size_t)S * sizeof(float);
@@ -1197,14 +1279,14 @@ int mvn_vnet_decode_f32(const float *y, int64_t y_ld, const float *W1, const flo
 int mvn_vnet_decode_count_f32(const float *y, int64_t y_ld, const float *W1, const float *b1, const float *W2,
                               const float *b2, const float *W3, const float *b3, const float *tx, int64_t tx_ld,
                               int32_t K, const uint8_t *row_mask, int64_t *counters, float *dec, int64_t dec_ld,
-                              int64_t B, int32_t T, int32_t S, mvn_stream_t stream) {
+                              void *workspace, size_t workspace_bytes, int64_t B, int32_t T, int32_t S, mvn_stream_t stream) {
     if (B < 0 || T < 0 || K < 0 || K > T || y_ld < T || tx_ld < K || (dec && dec_ld < T)) return MVN_E_DIMS;
     if (S != 16) return MVN_E_STATES;  // fused epilogue exists for the 16-state kernel only
     if (!counters) return MVN_E_NULL;
     if (B == 0 || T == 0) return MVN_OK;
     if (!y || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !tx) return MVN_E_NULL;
     return launch_vnet16_fused(y, y_ld, W1, b1, W2, b2, W3, b3, dec, dec_ld, nullptr, nullptr, B, T, tx, tx_ld, K,
-                               row_mask, (unsigned long long *)counters, (hipStream_t)stream);
+                               row_mask, (unsigned long long *)counters, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
 int mvn_vnet_online_train_f32(const float *y, const int32_t *labels, int32_t T, const int32_t *batch_idx, int32_t M,
@@ -1410,6 +1492,12 @@ void mvn_reload_switches(void) { load_switches(); }
 void mvn_test_hooks(int64_t group_spin_limit, int32_t group_phantoms) {
     if (group_spin_limit >= 0) g_group_spin_limit.store((unsigned)group_spin_limit, std::memory_order_relaxed);
     if (group_phantoms >= 0) g_group_phantoms.store(group_phantoms, std::memory_order_relaxed);
+}
+/* The dealt ViterbiNet kernel's hand-off between rings: ring `skip_ring` never publishes (-1: all do), and the waiting ring
+ * gives up after `spin_limit` polls (< 0: unchanged). */
+void mvn_test_hooks_dealt(int32_t skip_ring, int64_t spin_limit) {
+    g_dealt_skip_ring.store(skip_ring, std::memory_order_relaxed);
+    if (spin_limit >= 0) g_dealt_spin_limit.store((unsigned)spin_limit, std::memory_order_relaxed);
 }
 #endif
 

@@ -147,9 +147,10 @@ def _vnet_val(y: torch.Tensor, params, n_states: int, T: int, return_logits: boo
     logits = torch.empty((B, T, n_states), dtype=torch.float32, device=yc.device) if return_logits else None
     ws, ws_bytes = None, 0
     if logits is None:
-        ws_bytes = min(int(lib.mvn_vnet_workspace_bytes(B, T, n_states)), _WORKSPACE_CAP)
-        if ws_bytes:  # 0: the fused 16-state kernel needs no scratch
-            ws_bytes = max(ws_bytes, T * n_states * 4)
+        ws_bytes = int(lib.mvn_vnet_workspace_bytes(B, T, n_states))
+        if ws_bytes:  # 0: a fused kernel that needs no scratch
+            if n_states != 16:  # the two-kernel route's logits, in slices of at most _WORKSPACE_CAP (16 states: <= 100 KB of hand-off lines)
+                ws_bytes = max(min(ws_bytes, _WORKSPACE_CAP), T * n_states * 4)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=yc.device)
     with _lib.on_device(yc.device):
         rc = lib.mvn_vnet_decode_f32(_lib.ptr(yc), Ty, *[_lib.ptr(t) for t in w], _lib.ptr(decoded_word), Ty,
@@ -178,10 +179,13 @@ def _vnet_val_count(y, params, n_states, T, tx, rows=None, counters=None, return
         mask = torch.zeros(B, dtype=torch.uint8, device=yc.device)
         mask[rows.to(yc.device)] = 1
     dec = torch.zeros(yc.shape, dtype=torch.float32, device=yc.device) if return_decisions else None
+    ws_bytes = int(_lib.load().mvn_vnet_workspace_bytes(B, T, n_states)) if n_states == 16 else 0
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=yc.device) if ws_bytes else None  # the dealt kernel's hand-off lines
     with _lib.on_device(yc.device):
         rc = _lib.load().mvn_vnet_decode_count_f32(_lib.ptr(yc), Ty, *[_lib.ptr(t) for t in w], _lib.ptr(txc),
                                                    txc.stride(0), txc.shape[1], _lib.ptr(mask), _lib.ptr(counters),
-                                                   _lib.ptr(dec), Ty, B, T, n_states, _lib.current_stream(yc.device))
+                                                   _lib.ptr(dec), Ty, _lib.ptr(ws), ws_bytes, B, T, n_states,
+                                                   _lib.current_stream(yc.device))
     _lib.check(rc, "mvn_vnet_decode_count_f32")
     return (counters, dec) if return_decisions else counters
 

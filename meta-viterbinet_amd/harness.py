@@ -417,7 +417,10 @@ def _fused_step_applies(detector, rx: torch.Tensor, n_symbols: int, pass_count: 
         return False
     if isinstance(detector, VNETDetector):
         return not pass_count and detector.transmission_lengths["val"] == T
-    return isinstance(detector, VADetector) and detector.transmission_length == T
+    # VADetector: the fused step takes ONE row of state priors -- the word's own (pass_count) or the table's only row.  A
+    # multi-row table without the block number takes the separate launches, where the detector itself raises what the
+    # reference raises (the [1, S] / [W, S] broadcast of va_detector.py:64-68).
+    return isinstance(detector, VADetector) and detector.transmission_length == T and (pass_count or detector.val_words == 1)
 
 
 def _byword_step(detector, received_word: torch.Tensor, transmitted_word: torch.Tensor, n_symbols: int, pilot: bool,
@@ -439,8 +442,7 @@ def _byword_step(detector, received_word: torch.Tensor, transmitted_word: torch.
     enc = torch.empty((1, T), dtype=torch.float32, device=dev) if outputs else None
     if isinstance(detector, VADetector):
         pri = detector._priors_table(rxw, gamma, "val", count)  # [W, 16] (one row when count is given)
-        if pri.shape[0] != 1:
-            raise RuntimeError(f"The size of tensor a (1) must match the size of tensor b ({pri.shape[0]}) at non-singleton dimension 0")
+        assert pri.shape[0] == 1  # (_fused_step_applies sends every other table to the separate launches)
         with _lib.on_device(dev):
             rc = _lib.load().mvn_va_byword_step_f32(_lib.ptr(rxw), T, _lib.ptr(txw), K, _lib.ptr(pri), 1, _lib.ptr(det), T, None, K,
                                                     _lib.ptr(enc), T, None, T, None, T, _lib.ptr(nerr), 1, T, n_symbols,

@@ -37,7 +37,7 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.mvn_version() == 5
+    assert lib.mvn_version() == 6
     assert lib.mvn_strerror(0) == b"ok"
     for code in (-1, -2, -3, -4, -5, -6, -7, -99):
         assert lib.mvn_strerror(code).startswith(b"mvn:")

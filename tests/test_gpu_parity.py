@@ -3,6 +3,7 @@ libmvn_hip.so (via the ctypes binding) and is compared BIT-EXACTLY with (i) the 
 from the reference and (ii) the CPU oracle on seeded inputs.  The only tolerance anywhere is written in
 test_vnet_scalar_tail_tolerance (a property of torch-CPU, not of the kernels)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -333,9 +334,13 @@ def test_sweep16_quad_variant(oracle, dev, monkeypatch):
     assert (lib.mvn_va_decode_kernel_name(125000, 1000, 256, buf, 64), buf.value) == (0, b"va256_wave_kernel")
     assert (lib.mvn_va_decode_kernel_name(100, 1000, 16, buf, 64), buf.value) == (0, b"va16_tile_kernel")
     assert (lib.mvn_va_decode_kernel_name(10000, 1000, 16, buf, 64), buf.value) == (0, b"va16_quad_kernel")
-    assert (lib.mvn_vnet_decode_kernel_name(10000, 1000, 16, 0, buf, 64), buf.value) == (0, b"vnet16_fusedn_kernel<false, 2>")
+    assert (lib.mvn_vnet_decode_kernel_name(10000, 1000, 16, 0, buf, 64), buf.value) == (0, b"vnet16_dealt_kernel<false> rings of 1")
+    assert (lib.mvn_vnet_decode_kernel_name(1250, 1000, 16, 0, buf, 64), buf.value) == (0, b"vnet16_dealt_kernel<false> rings of 8")
     assert (lib.mvn_vnet_decode_kernel_name(1, 136, 16, 0, buf, 64), buf.value) == (0, b"vnet16_coop_kernel<false>")
-    assert (lib.mvn_vnet_decode_kernel_name(1, 2000, 16, 1, buf, 64), buf.value) == (0, b"vnet16_fusedn_kernel<true, 2>")  # T > 1024
+    assert (lib.mvn_vnet_decode_kernel_name(1, 2000, 16, 1, buf, 64), buf.value) == (0, b"vnet16_dealt_kernel<true> rings of 8")  # T > 1024
+    monkeypatch.setenv("MVN_DEALT", "0")  # (also what runs when the caller passes no hand-off workspace)
+    assert (lib.mvn_vnet_decode_kernel_name(10000, 1000, 16, 0, buf, 64), buf.value) == (0, b"vnet16_fusedn_kernel<false, 2>")
+    monkeypatch.delenv("MVN_DEALT")
     assert (lib.mvn_vnet_decode_kernel_name(10, 100, 64, 0, buf, 64), buf.value) == (0, b"vnet_fused_ip_kernel<4>")  # MLP inside the sweep
     assert (lib.mvn_vnet_decode_kernel_name(10, 100, 64, 1, buf, 64), buf.value) == (0, b"mlp_kernel<4> + sweep_inplace_kernel<4, 1, 4>")  # logits wanted
     assert (lib.mvn_vnet_decode_kernel_name(10, 100, 256, 0, buf, 64), buf.value) == (0, b"mlp_kernel<16> + sweep_inplace_kernel<6, 1, 4>")  # fused on request only
@@ -479,6 +484,136 @@ def test_fused_decode_count(oracle, dev, B, T, K):
     ser, fer, c4 = mvn.single_eval_at_point(det, tt, yt, 10, 0.2, torch.tensor(rows, device=dev))
     assert c4.tolist() == c2.tolist()
     assert mvn.count_errors(det(yt, "val")[:, :K], tt, torch.tensor(rows, device=dev)).tolist() == c2.tolist()
+
+
+def _dealt_call(lib, dev, yt, wt, B, T, want_logits=False, want_final=True, tx=None, K=0, mask=None):
+    """mvn_vnet_decode_f32 / mvn_vnet_decode_count_f32 with the workspace mvn_vnet_workspace_bytes asks for (the dealt kernel)."""
+    S = 16
+    nb = int(lib.mvn_vnet_workspace_bytes(B, T, S))
+    ws = torch.full((max(nb, 4),), 0x5A, dtype=torch.uint8, device=dev)  # (stale contents: the launch clears what it uses)
+    dec = torch.full((B, T), 7.0, device=dev)
+    lg = torch.empty(B, T, S, device=dev) if want_logits else None
+    fm = torch.empty(B, S, device=dev) if want_final else None
+    st = mvn._lib.current_stream(dev)
+    if tx is None:
+        rc = lib.mvn_vnet_decode_f32(mvn._lib.ptr(yt), yt.stride(0), *[mvn._lib.ptr(t) for t in wt], mvn._lib.ptr(dec), T, mvn._lib.ptr(lg),
+                                     mvn._lib.ptr(fm), mvn._lib.ptr(ws), nb, B, T, S, st)
+        assert rc == 0
+        return dec, lg, fm, ws, nb
+    c = torch.zeros(4, dtype=torch.int64, device=dev)
+    rc = lib.mvn_vnet_decode_count_f32(mvn._lib.ptr(yt), yt.stride(0), *[mvn._lib.ptr(t) for t in wt], mvn._lib.ptr(tx), tx.stride(0), K,
+                                       mvn._lib.ptr(mask), mvn._lib.ptr(c), mvn._lib.ptr(dec), T, mvn._lib.ptr(ws), nb, B, T, S, st)
+    assert rc == 0
+    return dec, c, ws, nb
+
+
+@pytest.mark.parametrize("B,T,coop,ring", [(769, 40, None, None), (1000, 136, None, None), (1250, 1000, None, None), (2048, 250, None, None),
+                                            (5000, 33, None, None), (777, 992, None, None), (3, 200, "0", None), (1, 45, "0", None),
+                                            (40, 1000, "0", None), (900, 1, None, None), (801, 31, None, None), (6200, 70, None, None),
+                                            (7000, 100, None, "8"), (7000, 100, None, "4"), (7000, 100, None, "2"), (7000, 100, None, None),
+                                            (3100, 130, None, "4"), (1600, 300, None, "2")])
+def test_vnet16_dealt_kernel_vs_oracle(oracle, dev, monkeypatch, B, T, coop, ring):
+    """vnet16_dealt_kernel (the batch's 32-symbol units shared evenly by 3 workgroups per CU, path metrics handed from wave to
+    wave): decisions, logits and final metrics equal the oracle's bit for bit -- more groups than blocks' worth of wave slots,
+    fewer blocks than groups (MVN_COOP=0 sends small batches here), units that end inside a tile, one symbol per block, every
+    ring size (8, 4, 2 waves handing the metrics round through LDS; 1: a wave's own range, metrics in registers) -- and the fused
+    error counters with a pilot mask equal the oracle's counts."""
+    S = 16
+    if coop is not None:
+        monkeypatch.setenv("MVN_COOP", coop)
+    if ring is not None:  # (a ring size the batch is too small for is raised to the smallest that fits: (1600, 300, "2") runs rings of 4)
+        monkeypatch.setenv("MVN_DEALT", ring)
+    lib = mvn._lib.load()
+    name = ctypes.create_string_buffer(96)
+    assert lib.mvn_vnet_decode_kernel_name(B, T, S, 0, name, 96) == 0 and name.value.decode().startswith("vnet16_dealt_kernel<false> rings of ")
+    rng = np.random.RandomState(B + 7 * T)
+    w = _rand_weights(S, rng)
+    y = rng.normal(0, 1.3, (B, T + 3)).astype(np.float32)  # (row stride > T)
+    yt, wt = torch.tensor(y, device=dev), _weights_t(w, dev)
+    rdec, rlg, rfm = oracle.vnet_decode(np.ascontiguousarray(y[:, :T]), w, want_logits=True, want_final=True)
+    dec, lg, fm, ws, nb = _dealt_call(lib, dev, yt, wt, B, T, want_logits=True)
+    assert nb > 0 and int(ws[:4].view(torch.int32).item()) == 0  # status word: no hand-off was abandoned
+    assert np.array_equal(_np(dec), rdec) and np.array_equal(_np(lg), rlg) and np.array_equal(_np(fm), rfm)
+    dec2, _, fm2, _, _ = _dealt_call(lib, dev, yt, wt, B, T, want_logits=False)
+    assert np.array_equal(_np(dec2), rdec) and np.array_equal(_np(fm2), rfm)
+    # fused counting, every fifth block a pilot
+    K = max(1, T - 5)
+    tx = rng.randint(0, 2, (B, K)).astype(np.float32)
+    rows = np.array([i for i in range(B) if i % 5 != 0] or [0], np.int64)
+    mask = torch.zeros(B, dtype=torch.uint8, device=dev)
+    mask[torch.tensor(rows, device=dev)] = 1
+    dec3, c, _, _ = _dealt_call(lib, dev, yt, wt, B, T, tx=torch.tensor(tx, device=dev), K=K, mask=mask)
+    assert np.array_equal(_np(dec3), rdec)
+    assert c.tolist() == oracle.count_errors(rdec[:, :K], tx, rows).tolist()
+
+
+@pytest.mark.parametrize("kind", ["nan_w3", "inf_b3", "nan_y"])
+def test_vnet16_dealt_kernel_follows_torch_min(oracle, dev, kind):
+    """Partially-NaN branch costs (a NaN weight of the last layer), an infinite bias and NaN samples: the dealt kernel's strict
+    stages / decisions give the oracle's (torch.min's, torch.argmin's) results across unit and group boundaries."""
+    S, B, T = 16, 1100, 200
+    rng = np.random.RandomState(5)
+    w = _rand_weights(S, rng)
+    y = rng.normal(0, 1.3, (B, T)).astype(np.float32)
+    if kind == "nan_w3":
+        w[4][3, 11] = np.nan
+    elif kind == "inf_b3":
+        w[5][6] = np.inf
+    else:
+        y[7, 90] = np.nan
+        y[800, 0] = np.inf
+    lib = mvn._lib.load()
+    dec, _, fm, _, _ = _dealt_call(lib, dev, torch.tensor(y, device=dev), _weights_t(w, dev), B, T)
+    rdec, rfm = oracle.vnet_decode(y, w, want_final=True)
+    assert np.array_equal(_np(dec), rdec) and np.array_equal(_np(fm), rfm, equal_nan=True)
+
+
+def test_vnet16_dealt_equals_one_wave_per_block_at_full_size(dev, monkeypatch):
+    """BASELINE configs[1] (10 000 x 1000) and its strong-scaled share (1 250 x 1000): the detector's default route -- the
+    dealt kernel, through VNETDetector.forward / val_count -- against the one-wave-per-block kernel (MVN_DEALT=0), which
+    test_config2_vnet_full_size pins to the oracle: same decisions, same counters."""
+    g7 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_by_word.npz"))
+    w = [g7[f"w{i}"] for i in range(6)]
+    for B in (10000, 1250):
+        tx, y = mvn.synthetic_words(B, 1000, 4, 10.0, 0.2, dev, seed=99 + B)
+        det = _vnet_with(w, 16, 1000, dev)
+        name = ctypes.create_string_buffer(96)
+        assert mvn._lib.load().mvn_vnet_decode_kernel_name(B, 1000, 16, 0, name, 96) == 0 and b"dealt" in name.value
+        dealt, c_dealt = det(y, "val"), det.val_count(y, tx)
+        monkeypatch.setenv("MVN_DEALT", "0")
+        assert mvn._lib.load().mvn_vnet_decode_kernel_name(B, 1000, 16, 0, name, 96) == 0 and b"fusedn" in name.value
+        plain, c_plain = det(y, "val"), det.val_count(y, tx)
+        monkeypatch.delenv("MVN_DEALT")
+        assert torch.equal(dealt, plain) and c_dealt.tolist() == c_plain.tolist() and c_dealt[3].item() == B
+
+
+def test_vnet16_dealt_abandoned_handoff_is_reported(dev, monkeypatch):
+    """The tests' build can keep one group from publishing the metrics of the block it shares with the next group: the waiting
+    group gives up after its (shortened) spin, sets the workspace's status word and stores NaN instead of decisions for the
+    rest of that block -- never a hang, never silent {0, 1} decisions."""
+    import __graft_entry__ as ge
+
+    lib = mvn._lib.load_variant(ge.build_hip_hooks())
+    lib.mvn_test_hooks_dealt.restype, lib.mvn_test_hooks_dealt.argtypes = None, [ctypes.c_int32, ctypes.c_int64]
+    lib.mvn_reload_switches()
+    B, T = 1000, 200  # 768 groups: 7000 units, 9.1 per group -> most blocks cross a group boundary
+    rng = np.random.RandomState(2)
+    w = _rand_weights(16, rng)
+    yt, wt = torch.tensor(rng.normal(0, 1, (B, T)).astype(np.float32), device=dev), _weights_t(w, dev)
+    ok_dec, _, _, ws, _ = _dealt_call(lib, dev, yt, wt, B, T)
+    assert int(ws[:4].view(torch.int32).item()) == 0 and not bool(torch.isnan(ok_dec).any())
+    try:
+        lib.mvn_test_hooks_dealt(5, 2000)
+        dec, _, _, ws, _ = _dealt_call(lib, dev, yt, wt, B, T)
+        torch.cuda.synchronize()
+        assert int(ws[:4].view(torch.int32).item()) == 1
+        bad_rows = torch.isnan(dec).any(dim=1).nonzero().flatten().tolist()
+        assert len(bad_rows) == 1  # the one block groups 5 and 6 share
+        good = torch.ones(B, dtype=torch.bool, device=dev)
+        good[bad_rows[0]] = False
+        assert torch.equal(dec[good], ok_dec[good])
+    finally:
+        lib.mvn_test_hooks_dealt(-1, 1 << 21)
 
 
 def test_detector_api_contract(dev):

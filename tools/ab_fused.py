@@ -35,7 +35,7 @@ counters = torch.zeros(4, dtype=torch.int64, device=dev)
 def run():
     if COUNT:  # decode + fused error counting, no decision store
         rc = lib.mvn_vnet_decode_count_f32(mvn._lib.ptr(y), T, *[mvn._lib.ptr(t) for t in w], mvn._lib.ptr(tx), T, T, None,
-                                           mvn._lib.ptr(counters), None, T, B, T, S, st)
+                                           mvn._lib.ptr(counters), None, T, None, 0, B, T, S, st)
     else:
         rc = lib.mvn_vnet_decode_f32(mvn._lib.ptr(y), T, *[mvn._lib.ptr(t) for t in w], mvn._lib.ptr(dec), T, None, None, None,
                                      0, B, T, S, st)
