@@ -481,6 +481,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=10000, help="blocks per GPU (BASELINE configs[1]: 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained-rate loop")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling entry (the same 10 000 blocks split over the ranks)")
     ap.add_argument("--sustained-seconds", type=float, default=2.0)
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config entries (BASELINE configs[0],[2],[3],[4])")
     ap.add_argument("--skip-fused-count", action="store_true", help="(profiling) keep every fused-kernel dispatch decode-only: no fused-count timing, no FER curve, no by-word configs")
@@ -609,6 +610,48 @@ def main():
         fer_curve.append({"snr_db": snr_db, "ser": s_, "fer": f_, "frames": int(c[3].item())})
         del txs, ys
 
+    # ---- strong scaling of the same workload: BASELINE configs[1]'s 10 000 blocks SPLIT over the ranks (the reference calls the
+    # detector with whatever its evaluation holds, trainer.py:232), next to the weak-scaling headline above.  Outside `value`.
+    strong = None
+    if not args.no_strong:
+        lo_s, hi_s = mvn.shard_range(args.blocks, rank, world)
+        ys, txs_ = y[lo_s:hi_s], tx[lo_s:hi_s]  # (rank r's share of ITS 10 000 words: same distribution on every rank)
+        cs = torch.zeros(4, dtype=torch.int64, device=dev)
+
+        def step_strong():
+            mvn.count_errors(det(ys, "val", SNR_DB, GAMMA), txs_, None, cs)
+
+        for _ in range(max(args.warmup, 5)):
+            step_strong()
+        cs.zero_()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0s = time.perf_counter()
+        for _ in range(args.steps):
+            step_strong()
+        if world > 1:
+            all_reduce(cs)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        el_s = time.perf_counter() - t0s
+        if world > 1:
+            te = torch.tensor([el_s], dtype=torch.float64, device=dev)
+            all_reduce(te, op=dist.ReduceOp.MAX)
+            el_s = float(te.item())
+        nb_s = hi_s - lo_s
+        kname = ctypes.create_string_buffer(96)
+        mvn._lib.load().mvn_vnet_decode_kernel_name(nb_s, T, S, 0, kname, 96)
+        strong = {"scaling": "strong", "total_blocks": args.blocks, "blocks_per_gpu": nb_s, "steps": args.steps,
+                  "ms_per_step": el_s / args.steps * 1e3, "symbols_per_s": args.blocks * T * args.steps / el_s,
+                  "frames_counted": int(cs[3].item()), "frames_expected": args.blocks * args.steps, "kernel": kname.value.decode(),
+                  "mfma_frac_of_this_rank": FLOP_PER_SYMBOL * nb_s * T / (el_s / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                  "what": f"the SAME {args.blocks} blocks x {T} symbols split over {world} rank(s) (contiguous shares, harness.shard_range), "
+                          "forward('val') + on-device counting per step, one all-reduce of int64[4] at the end, max over ranks; the "
+                          "per-rank fraction includes the counting launch"}
+
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel, timed alone with HIP events on its launch stream
@@ -616,8 +659,10 @@ def main():
         st = mvn._lib.current_stream(dev)
         wp = [mvn._lib.ptr(w) for w in weights]
         dec = torch.zeros(B, T, device=dev)
+        ws_bytes = int(lib.mvn_vnet_workspace_bytes(B, T, S))  # the dealt kernel's hand-off lines (what VNETDetector.forward passes)
+        ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
         ms_fused = event_time_ms(lambda: lib.mvn_vnet_decode_f32(mvn._lib.ptr(y), T, *wp, mvn._lib.ptr(dec), T, None, None,
-                                                                 None, 0, B, T, S, st), 5, dev)
+                                                                 mvn._lib.ptr(ws), ws_bytes, B, T, S, st), 5, dev)
         # secondary: the HBM-bound ACS sweep over materialised costs (mvn_acs_sweep_f32), same B x T x S
         cost = torch.randn(B, T, S, device=dev)
         ms_acs = event_time_ms(lambda: lib.mvn_acs_sweep_f32(mvn._lib.ptr(cost), mvn._lib.ptr(dec), T, None, B, T, S, st),
@@ -666,6 +711,7 @@ def main():
                                    "ms_per_launch": ms_acs,
                                    "bytes_per_symbol": ACS_BYTES_PER_SYMBOL},
             "ms_per_step_events": ms_step,
+            "strong_scaling": strong,
             "fused_decode_count": {"what": "mvn_vnet_decode_count_f32: decode + error counting in one launch, no decision "
                                            "store (4 B/symbol of HBM traffic); same counters as `value`'s two-launch step",
                                    "ms_per_step": ms_fused_count, "symbols_per_s": B * T / (ms_fused_count * 1e-3)},

@@ -20,17 +20,15 @@
  *   - arithmetic is IEEE fp32 with one rounding per reference operation; results are
  *     bit-identical to oracle/mvn_oracle.c for finite inputs, for +-inf, and for NaN -- in the samples y, in the weights
  *     and in the state priors: mvn_acs_block_f32, mvn_va_decode_f32, mvn_vnet_decode_f32 (every route, every S),
- *     mvn_vnet_decode_count_f32 and mvn_vnet_byword_step_f32 follow torch.min / torch.argmin (NaN when either candidate is
- *     NaN; the first NaN, else the first minimum).  The fast kernels' ACS stage is v_min_f32 (minNum), which agrees with
- *     torch.min unless SOME BUT NOT ALL of a symbol's branch costs are NaN; from y, weights and priors that takes a
- *     non-finite (or > 1e14 in magnitude) weight or prior, which the kernels look for once per launch and then run their
- *     NaN-propagating form (16-state kernels) or are followed by a guard launch of the generic kernel that re-decodes the
- *     affected blocks (sweep_kernel<S, MODE, true>: an early-exit no-op otherwise).
- *     REMAINING DEVIATION, pinned by tests/test_gpu_parity.py::test_partial_nan_costs_are_dropped_by_the_sweeps:
- *     mvn_acs_sweep_f32 takes MATERIALISED costs, which nothing vouches for: its specialised kernels drop a NaN that sits
- *     in only one of a state's two candidates (a state both of whose candidates are NaN becomes NaN, and the decision rule
- *     is torch.argmin's); S = 2, buffers that are not 16-byte aligned and MVN_GENERIC_SWEEP=1 take the generic kernel,
- *     which follows torch.min there too.
+ *     mvn_acs_sweep_f32, mvn_vnet_decode_count_f32 and mvn_vnet_byword_step_f32 follow torch.min / torch.argmin (NaN when
+ *     either candidate is NaN; the first NaN, else the first minimum).  The fast kernels' ACS stage is v_min_f32 (minNum),
+ *     which agrees with torch.min unless SOME BUT NOT ALL of a symbol's branch costs are NaN (or +inf meets -inf in a path
+ *     metric).  From y, weights and priors that takes a non-finite (or > 1e14 in magnitude) weight or prior, which the kernels
+ *     look for once per launch and then run their NaN-propagating form (16-state kernels) or are followed by a guard launch of
+ *     the generic kernel that re-decodes the affected blocks (sweep_kernel<S, MODE, true>: an early-exit no-op otherwise).
+ *     MATERIALISED costs (mvn_acs_sweep_f32; the logits of the two-kernel ViterbiNet route) are tested one by one on their way
+ *     into the recurrence: from the first cost that is NaN, infinite or >= 1e30 in magnitude on, a wave runs the
+ *     NaN-propagating stage and decision.
  */
 #ifndef MVN_H_
 #define MVN_H_

@@ -111,7 +111,10 @@ def test_bench_self_launch_four_ranks_with_configs():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 4
     _check_collective_fields(out, 4, 512, 2)
-    assert out["cpu_baseline"]["value"] > 0 and out["sustained"]["symbols_per_s"] > 0
+    # the CPU baselines are timed at N = 1 only (the other ranks would sit in a barrier for ~30 s): at N > 1 the entry says so
+    assert out["cpu_baseline"]["value"] is None and "N=1" in out["cpu_baseline"]["sample"] and out["sustained"]["symbols_per_s"] > 0
+    strong = out["strong_scaling"]  # the same 512 blocks split over the 4 ranks, next to the weak-scaling headline
+    assert strong["blocks_per_gpu"] == 128 and strong["frames_counted"] == strong["frames_expected"] == 512 * out["steps"]
     cfg = {c["config"].split(":")[0]: c for c in out["configs"]}
     assert cfg["BASELINE configs[3]"]["frames"] == 4 * 125000  # all ranks' blocks in the all-reduced counters
     assert cfg["BASELINE configs[2]"]["self_supervised_trials"]["trials_per_gpu"] == 6

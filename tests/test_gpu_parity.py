@@ -1374,42 +1374,57 @@ def test_acs_block_propagates_nan_like_torch_min(oracle, dev):
         assert np.array_equal(_np(arg), rj)
 
 
-@pytest.mark.parametrize("S,variant", [(4, ""), (16, "rows"), (16, "lds"), (16, "quad"), (16, "inplace"), (16, "generic"),
-                                       (64, ""), (64, "generic"), (256, "")])
-def test_partial_nan_costs_are_dropped_by_the_sweeps(oracle, dev, monkeypatch, S, variant):
-    """The documented deviation of include/mvn.h, now confined to mvn_acs_sweep_f32 over MATERIALISED costs: its specialised
-    kernels' ACS minimum is v_min_f32 (= fminf), which drops a NaN that sits in only ONE of a state's two candidates, where
-    torch.min would return NaN.  Pinned against a NumPy model with np.fmin; the decision rule (first NaN, else first
-    minimum) is np.argmin's = torch.argmin's.  The generic kernel (S = 2, unaligned buffers, MVN_GENERIC_SWEEP=1) takes
-    torch.min's rule and is compared with the oracle."""
-    rng = np.random.RandomState(S)
-    B, T = 6, 40
+SWEEP_VARIANTS = [(4, ""), (8, ""), (16, "rows"), (16, "lds"), (16, "quad"), (16, "inplace"), (16, "generic"), (16, "unaligned"),
+                  (32, ""), (64, ""), (64, "generic"), (128, ""), (256, ""), (2, "")]
+
+
+@pytest.mark.parametrize("S,variant", SWEEP_VARIANTS)
+@pytest.mark.parametrize("what", ["partial_nan", "inf_then_minus_inf", "huge", "late_nan"])
+def test_sweeps_follow_torch_min_on_odd_costs(oracle, dev, monkeypatch, S, variant, what):
+    """mvn_acs_sweep_f32 takes MATERIALISED costs, which nothing vouches for: every kernel that serves it (rows / lds / quad /
+    in-place at every S, the generic one, unaligned buffers) must give oracle.acs_sweep's decisions and final metrics --
+    torch.min's rule (trellis_utils.py:28-30: NaN when EITHER candidate of a state is NaN) and torch.argmin's (the first NaN,
+    else the first minimum) -- when a NaN sits in only one of a state's two candidates, when +inf meets -inf in a path metric,
+    when costs are so large that their sums overflow, and when the first odd cost comes late in a block (the kernels test every
+    cost on its way into the recurrence and switch to the NaN-propagating stage from there on).  Until round 4 the
+    specialised kernels dropped such a NaN (v_min_f32 = minNum); that deviation is gone."""
+    rng = np.random.RandomState(S + len(what))
+    B, T = 37, 83  # several waves of the quad / lds kernels, a partial last chunk
     cost = rng.normal(0, 2, (B, T, S)).astype(np.float32)
-    for b in range(B):
-        for t in rng.choice(T, 4, replace=False):
-            cost[b, t, rng.randint(S)] = np.nan
-    cost[2, 7, :] = np.nan  # a whole symbol: every metric turns NaN from here on, decisions 0
+    if what == "partial_nan":
+        for b in range(0, B, 2):
+            for t in rng.choice(T, 3, replace=False):
+                cost[b, t, rng.randint(S)] = np.nan
+        cost[2, 7, :] = np.nan  # a whole symbol: every metric turns NaN from here on, decisions 0
+    elif what == "inf_then_minus_inf":
+        for b in range(0, B, 3):
+            cost[b, 5, rng.randint(S)] = np.inf
+            cost[b, 30, :] = -np.inf if b % 2 else np.inf
+            cost[b, 31, rng.randint(S)] = -np.inf
+    elif what == "huge":
+        cost[::4, 10:14, :] *= 1e37
+        cost[1::4, 20, 0] = -3e38
+    else:
+        cost[B - 1, T - 2, S - 1] = np.nan
+        cost[5, T - 1, 0] = np.nan  # in the last step: only the final metrics see it
     if variant in ("rows", "lds", "quad"):
         monkeypatch.setenv("MVN_SWEEP16", variant)
     elif variant == "inplace":
         monkeypatch.setenv("MVN_SWEEP_INPLACE", "1")
     elif variant == "generic":
         monkeypatch.setenv("MVN_GENERIC_SWEEP", "1")
-    if variant == "generic":
-        want_dec, m = oracle.acs_sweep(cost)
-    else:
-        want_dec = np.zeros((B, T), np.float32)
-        m = np.zeros((B, S), np.float32)
-        idx = np.arange(S)
-        with np.errstate(invalid="ignore"):
-            for t in range(T):
-                want_dec[:, t] = np.argmin(m, axis=1) % 2
-                a = m + cost[:, t]
-                m = np.fmin(a[:, (2 * idx) % S], a[:, (2 * idx + 1) % S])
-    dec, fm = mvn.acs_sweep(torch.tensor(cost, device=dev), return_final=True)
-    assert np.array_equal(_np(fm), m, equal_nan=True)
+    with np.errstate(invalid="ignore", over="ignore"):
+        want_dec, want_m = oracle.acs_sweep(cost)
+    ct = torch.tensor(cost, device=dev)
+    if variant == "unaligned":  # costs one float into their allocation: the row kernel
+        buf = torch.empty(cost.size + 1, device=dev)
+        ct = buf[1:].view(B, T, S)
+        ct.copy_(torch.tensor(cost))
+    dec, fm = mvn.acs_sweep(ct, return_final=True)
     assert np.array_equal(_np(dec), want_dec)
-    assert np.isnan(m[2]).all() and (variant == "generic" or not np.isnan(m[0]).all())
+    assert np.array_equal(_np(fm), want_m, equal_nan=True)
+    if what == "partial_nan":
+        assert np.isnan(want_m[2]).all() and np.isnan(want_m[0]).all() and not np.isnan(want_m[1]).any()
 
 
 VNET_NAN_ROUTES = [(16, {"MVN_COOP": "1"}), (16, {"MVN_COOP": "0"}), (16, {"MVN_COOP": "0", "MVN_FUSEDN": "4"}),
