@@ -52,7 +52,7 @@ typedef void *mvn_stream_t; /* hipStream_t */
 
 #define MVN_E_BARRIER (-7)   /* (status words only) a training launch abandoned its device-wide barrier */
 
-#define MVN_ABI_VERSION 6 /* 6: workspace arguments on mvn_vnet_decode_count_f32 (the dealt 16-state kernel's hand-off lines); 5: + mvn_vnet_train_kernel_name, mvn_va_byword_step_f32; 4: + trial-batched training / by-word step, status words; 3: training with a workspace; 2: kernel-name queries */
+#define MVN_ABI_VERSION 6 /* 6: workspace arguments on mvn_vnet_decode_count_f32 (the dealt 16-state kernel's hand-off lines), + the survivor / traceback entry points; 5: + mvn_vnet_train_kernel_name, mvn_va_byword_step_f32; 4: + trial-batched training / by-word step, status words; 3: training with a workspace; 2: kernel-name queries */
 
 /* ABI version of the loaded library (== MVN_ABI_VERSION). */
 int mvn_version(void);
@@ -79,6 +79,27 @@ int mvn_acs_block_f32(const float *in_prob, const float *llrs, float *out, int64
  *   cost [B,T,S] contiguous; dec [B, dec_ld>=T]; final_metric [B,S] or NULL.
  */
 int mvn_acs_sweep_f32(const float *cost, float *dec, int64_t dec_ld, float *final_metric,
+                      int64_t B, int32_t T, int32_t S, mvn_stream_t stream);
+
+/*
+ * The same two sweeps WITH survivor (traceback) pointers -- optional: the reference computes them and drops them (acs_block
+ * returns (values, argmin_j), python_code/utils/trellis_utils.py:30; its callers keep the values only, va_detector.py:95,
+ * vnet_detector.py:57), so nothing on the parity path stores or reads them.  dec and final_metric are bit for bit those of
+ * mvn_acs_sweep_f32 / mvn_va_decode_f32; in addition
+ *     surv[b][t][s >> 3] bit (s & 7) = argmin_j of state s at stage t  (torch.min's index: the first minimum, the first NaN),
+ *     the predecessor of state s on its surviving path being (2 s + j) % S            (trellis_utils.py:7-13)
+ * i.e. max(1, S / 8) bytes per symbol, mvn_survivor_bytes(B, T, S) in all, any alignment (line-aligned rows are written as whole
+ * 128-byte lines).  mvn_traceback_f32 walks them back from torch.argmin(final_metric[b]) and returns the textbook
+ * maximum-likelihood path: bits [B, bits_ld >= T] fp32 {0,1}, bits[b][t] = the least-significant bit of the path's state before
+ * stage t (the bit of symbol t, trellis_utils.py:33-46); states int32 [B, T] = those states, or NULL.
+ */
+size_t mvn_survivor_bytes(int64_t B, int32_t T, int32_t S);
+int mvn_acs_sweep_surv_f32(const float *cost, float *dec, int64_t dec_ld, float *final_metric, uint8_t *surv,
+                           int64_t B, int32_t T, int32_t S, mvn_stream_t stream);
+int mvn_va_decode_surv_f32(const float *y, int64_t y_ld, const float *state_priors, int64_t Bp, float *dec,
+                           int64_t dec_ld, float *final_metric, uint8_t *surv, int64_t B, int32_t T, int32_t S,
+                           mvn_stream_t stream);
+int mvn_traceback_f32(const uint8_t *surv, const float *final_metric, float *bits, int64_t bits_ld, int32_t *states,
                       int64_t B, int32_t T, int32_t S, mvn_stream_t stream);
 
 /*

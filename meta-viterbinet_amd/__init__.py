@@ -10,11 +10,11 @@ from .meta import GraphedMetaStep, copy_model, meta_train_loop
 from .online import OnlineTrainer
 from .trials import TrialBank, TrialDraws, eval_by_word_batched
 from .metrics import calculate_error_rates, count_errors, rates_from_counters
-from .trellis import acs_block, acs_sweep, calculate_states, create_transition_table
+from .trellis import acs_block, acs_sweep, acs_sweep_survivors, calculate_states, create_transition_table, traceback
 
 __all__ = [
     "VADetector", "VNETDetector", "META_VNETDetector", "HIDDEN1_SIZE", "HIDDEN2_SIZE",
-    "create_transition_table", "acs_block", "acs_sweep", "calculate_states",
+    "create_transition_table", "acs_block", "acs_sweep", "acs_sweep_survivors", "traceback", "calculate_states",
     "calculate_error_rates", "count_errors", "rates_from_counters",
     "estimate_channel", "BPSKModulator", "transmit", "generate_words", "ReferenceWordStream", "rs_encode", "rs_decode", "OnlineTrainer", "meta_train_loop", "GraphedMetaStep", "copy_model",
     "shard_range", "data_indices", "synthetic_words", "eval_counters", "single_eval_at_point",

@@ -23,6 +23,10 @@ SIGNATURES = {
                                        ctypes.c_char_p, ctypes.c_int]),
     "mvn_acs_block_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "mvn_acs_sweep_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
+    "mvn_survivor_bytes": (ctypes.c_size_t, [_i64, _i32, _i32]),
+    "mvn_acs_sweep_surv_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "mvn_va_decode_surv_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "mvn_traceback_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
     "mvn_acs_sweep_kernel_name": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i32, _i32, ctypes.c_char_p, _i32]),
     "mvn_va_decode_kernel_name": (ctypes.c_int, [_i64, _i32, _i32, ctypes.c_char_p, _i32]),
     "mvn_vnet_decode_kernel_name": (ctypes.c_int, [_i64, _i32, _i32, _i32, ctypes.c_char_p, _i32]),

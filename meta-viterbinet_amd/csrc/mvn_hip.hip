@@ -419,6 +419,8 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 
 int current_device_cus();  // CUs of the current device, cached per device (defined below the kernels)
 
+#include "sweep_surv.inc"
+
 #include "vnet16_fused.inc"
 #include "vnet16_fusedn.inc"
 #include "vnet16_dealt.inc"
@@ -1170,6 +1172,41 @@ int mvn_acs_sweep_f32(const float *cost, float *dec, int64_t dec_ld, float *fina
     if (!cost || !dec) return MVN_E_NULL;
     return dispatch_sweep<MODE_COST>(cost, 0, nullptr, 1, dec, dec_ld, final_metric, B, T, S,
                                    (hipStream_t)stream);
+}
+
+size_t mvn_survivor_bytes(int64_t B, int32_t T, int32_t S) {
+    if (B <= 0 || T <= 0 || !valid_states(S)) return 0;
+    return (size_t)B * (size_t)T * (size_t)(S >= 8 ? S / 8 : 1);
+}
+
+int mvn_acs_sweep_surv_f32(const float *cost, float *dec, int64_t dec_ld, float *final_metric, uint8_t *surv, int64_t B, int32_t T,
+                           int32_t S, mvn_stream_t stream) {
+    if (B < 0 || T < 0 || dec_ld < T) return MVN_E_DIMS;
+    if (!valid_states(S)) return MVN_E_STATES;
+    if (B == 0 || T == 0) return MVN_OK;
+    if (!cost || !dec || !surv) return MVN_E_NULL;
+    return launch_sweep_surv<MODE_COST>(cost, 0, nullptr, 1, dec, dec_ld, final_metric, surv, B, T, S, (hipStream_t)stream);
+}
+
+int mvn_va_decode_surv_f32(const float *y, int64_t y_ld, const float *state_priors, int64_t Bp, float *dec, int64_t dec_ld,
+                           float *final_metric, uint8_t *surv, int64_t B, int32_t T, int32_t S, mvn_stream_t stream) {
+    if (B < 0 || T < 0 || dec_ld < T || y_ld < T) return MVN_E_DIMS;
+    if (!valid_states(S)) return MVN_E_STATES;
+    if (Bp < 1 || (B % Bp) != 0) return MVN_E_PRIORS;
+    if (B == 0 || T == 0) return MVN_OK;
+    if (!y || !state_priors || !dec || !surv) return MVN_E_NULL;
+    return launch_sweep_surv<MODE_VA>(y, y_ld, state_priors, Bp, dec, dec_ld, final_metric, surv, B, T, S, (hipStream_t)stream);
+}
+
+int mvn_traceback_f32(const uint8_t *surv, const float *final_metric, float *bits, int64_t bits_ld, int32_t *states, int64_t B,
+                      int32_t T, int32_t S, mvn_stream_t stream) {
+    if (B < 0 || T < 0 || bits_ld < T) return MVN_E_DIMS;
+    if (!valid_states(S)) return MVN_E_STATES;
+    if (B == 0 || T == 0) return MVN_OK;
+    if (!surv || !final_metric || !bits) return MVN_E_NULL;
+    hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, surv, final_metric, bits,
+                       bits_ld, states, B, T, S);
+    return (int)hipGetLastError();
 }
 
 int mvn_acs_sweep_kernel_name(const float *cost, const float *dec, int64_t dec_ld, int64_t B, int32_t T, int32_t S,

@@ -126,6 +126,39 @@ class VADetector(nn.Module):
         return decoded_word
 
 
+def _va_viterbi_path(self, y: torch.Tensor, snr: float = None, gamma: float = None, count: int = None, return_all: bool = False):
+    """Textbook Viterbi detection with survivor-path traceback -- NOT what the reference's VADetector.forward returns (it decides
+    every symbol from a running argmin and drops acs_block's survivor indices, va_detector.py:93-95): the same
+    sweep with the survivors kept (mvn_va_decode_surv_f32), then the traceback from the best final metric.  Returns the
+    maximum-likelihood bits [B, y.shape[1]] (columns >= transmission_length zero), or with return_all
+    (bits, running decisions = forward(y,'val'), final metrics, survivors)."""
+    from .trellis import traceback
+
+    _lib.require_gpu_tensor(y, "y")
+    yc = _as_f32(y)
+    B, Ty = yc.shape
+    T = self.transmission_length
+    pri = self._priors_table(yc, gamma, "val", count)
+    W = pri.shape[0]
+    if B % W != 0:
+        raise RuntimeError(f"The size of tensor a ({B}) must match the size of tensor b ({W * (B // W)}) at non-singleton dimension 0")
+    _check_T(T, yc)
+    dec = _new_decisions(yc, T)
+    S = self.n_states
+    fm = torch.empty((B, S), dtype=torch.float32, device=yc.device)
+    surv = torch.empty((B, T, max(1, S // 8)), dtype=torch.uint8, device=yc.device)
+    with _lib.on_device(yc.device):
+        rc = _lib.load().mvn_va_decode_surv_f32(_lib.ptr(yc), Ty, _lib.ptr(pri), W, _lib.ptr(dec), Ty, _lib.ptr(fm), _lib.ptr(surv),
+                                                B, T, S, _lib.current_stream(yc.device))
+    _lib.check(rc, "mvn_va_decode_surv_f32")
+    bits = torch.zeros_like(yc)
+    bits[:, :T] = traceback(surv, fm)
+    return (bits, dec, fm, surv) if return_all else bits
+
+
+VADetector.viterbi_path = _va_viterbi_path
+
+
 def _weights_on(params, device, n_states):
     w = [_as_f32(p) if p.device == device else _as_f32(p).to(device) for p in params]
     if (len(w) != 6 or w[0].shape != (HIDDEN1_SIZE, 1) or w[1].shape != (HIDDEN1_SIZE,) or w[2].shape != (HIDDEN2_SIZE, HIDDEN1_SIZE)

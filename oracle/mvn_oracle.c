@@ -137,6 +137,60 @@ int mvn_oracle_acs_sweep(const float *cost, float *dec, int64_t dec_ld, float *f
     return 0;
 }
 
+/* The same stage keeping torch.min's indices (trellis_utils.py:30: `return torch.min(...)` = (values, argmin_j)): bit (s & 7) of
+ * sv[s >> 3] = j, the surviving predecessor of state s being (2s + j) % S.  The reference's callers drop them
+ * (va_detector.py:95, vnet_detector.py:57); the survivor entry points of the HIP library store them. */
+static inline void acs_stage_inplace_surv(float *m, const float *c, int S, uint8_t *sv) {
+    float a[MVN_MAX_S];
+    const int SB = S >= 8 ? S / 8 : 1;
+    for (int p = 0; p < S; ++p) a[p] = m[p] + c[p];
+    memset(sv, 0, (size_t)SB);
+    for (int s = 0; s < S; ++s) {
+        int64_t j;
+        m[s] = min2_torch(a[(2 * s) % S], a[(2 * s + 1) % S], &j);
+        sv[s >> 3] |= (uint8_t)(j << (s & 7));
+    }
+}
+
+/* mvn_oracle_acs_sweep + the survivors surv[b][t][max(1, S/8)] */
+int mvn_oracle_acs_sweep_surv(const float *cost, float *dec, int64_t dec_ld, float *final_metric, uint8_t *surv,
+                              int64_t B, int T, int S) {
+    int rc = check_dims(B, T, S);
+    if (rc) return rc;
+    const int SB = S >= 8 ? S / 8 : 1;
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; ++b) {
+        float m[MVN_MAX_S];
+        for (int s = 0; s < S; ++s) m[s] = 0.0f;
+        const float *cb = cost + (size_t)b * (size_t)T * (size_t)S;
+        for (int t = 0; t < T; ++t) {
+            dec[b * dec_ld + t] = (float)(argmin_torch(m, S) % 2);
+            acs_stage_inplace_surv(m, cb + (size_t)t * S, S, surv + ((size_t)b * T + t) * SB);
+        }
+        if (final_metric) memcpy(final_metric + b * S, m, sizeof(float) * (size_t)S);
+    }
+    return 0;
+}
+
+/* Textbook traceback over those survivors: sigma_T = torch.argmin(final_metric[b]); sigma_t = (2 sigma_{t+1} + j) % S;
+ * bits[b][t] = sigma_t & 1 (the state before stage t pays cost[b][t][sigma_t]; its LSB is symbol t's bit, trellis_utils.py:33-46). */
+int mvn_oracle_traceback(const uint8_t *surv, const float *final_metric, float *bits, int64_t bits_ld, int32_t *states,
+                         int64_t B, int T, int S) {
+    int rc = check_dims(B, T, S);
+    if (rc) return rc;
+    const int SB = S >= 8 ? S / 8 : 1;
+    for (int64_t b = 0; b < B; ++b) {
+        int s = argmin_torch(final_metric + b * S, S);
+        for (int t = T - 1; t >= 0; --t) {
+            const int j = (surv[((size_t)b * T + t) * SB + (s >> 3)] >> (s & 7)) & 1;
+            s = (2 * s + j) % S;
+            bits[b * bits_ld + t] = (float)(s & 1);
+            if (states) states[(size_t)b * T + t] = s;
+        }
+    }
+    return 0;
+}
+
 /* va_detector.py:64-68: cost[b][t][s] for rows of y; priors is [Bp][S], Bp in {1,B}
  * (the reference repeats the [W,S] table B//W times, i.e. row b uses priors[b % Bp]). */
 #define MVN_LOG_SQRT_2PI_F ((float)0.91893853320467274178)

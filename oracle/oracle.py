@@ -85,6 +85,33 @@ def acs_sweep(cost, want_final=True):
     return (dec, fm) if want_final else dec
 
 
+def acs_sweep_surv(cost):
+    """acs_sweep + the survivors: dec [B,T], final metrics [B,S], surv uint8 [B,T,max(1,S/8)] (bit s & 7 of byte s >> 3 = torch.min's
+    index j of state s; predecessor (2s + j) % S: trellis_utils.py:7-13,30)."""
+    c = _f32(cost)
+    B, T, S = c.shape
+    dec = np.zeros((B, T), np.float32)
+    fm = np.empty((B, S), np.float32)
+    surv = np.zeros((B, T, max(1, S // 8)), np.uint8)
+    _check(lib().mvn_oracle_acs_sweep_surv(_p(c), _p(dec), ctypes.c_int64(T), _p(fm), surv.ctypes.data_as(ctypes.c_void_p),
+                                           ctypes.c_int64(B), ctypes.c_int(T), ctypes.c_int(S)), "acs_sweep_surv")
+    return dec, fm, surv
+
+
+def traceback(surv, final_metric):
+    """The textbook maximum-likelihood path from the survivors: bits [B,T] fp32 {0,1}, states int32 [B,T]."""
+    sv = np.ascontiguousarray(surv, dtype=np.uint8)
+    fm = _f32(final_metric)
+    B, T = sv.shape[:2]
+    S = fm.shape[1]
+    bits = np.zeros((B, T), np.float32)
+    states = np.zeros((B, T), np.int32)
+    _check(lib().mvn_oracle_traceback(sv.ctypes.data_as(ctypes.c_void_p), _p(fm), _p(bits), ctypes.c_int64(T),
+                                      states.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(B), ctypes.c_int(T), ctypes.c_int(S)),
+           "traceback")
+    return bits, states
+
+
 def va_costs(y, priors, T=None):
     """va_detector.py:64-68 -> cost [B,T,S]"""
     y, pr = _f32(y), _f32(priors)

@@ -1374,6 +1374,53 @@ def test_acs_block_propagates_nan_like_torch_min(oracle, dev):
         assert np.array_equal(_np(arg), rj)
 
 
+@pytest.mark.parametrize("S", [2, 4, 8, 16, 32, 64, 128, 256])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 7), (5, 64), (67, 129), (130, 33), (9, 1000)])
+def test_survivor_sweep_vs_oracle(oracle, dev, S, B, T):
+    """mvn_acs_sweep_surv_f32 (the optional traceback pointers of BASELINE's north_star; the reference computes and
+    drops them, trellis_utils.py:30): decisions and final metrics bit for bit those of mvn_acs_sweep_f32, the survivor planes
+    [B, T, max(1, S/8)] bit for bit the oracle's (= acs_block's argmin_j, pinned to G1 in test_oracle_golden), and
+    mvn_traceback_f32's path = the oracle's = the textbook Viterbi path; odd costs (a NaN, exact ties) included."""
+    rng = np.random.RandomState(S * 1000 + B * 10 + T)
+    cost = rng.normal(0, 2, (B, T, S)).astype(np.float32)
+    cost[B // 2] = np.round(cost[B // 2])  # exact ties: the first minimal index wins
+    if T > 5 and B > 2:
+        cost[1, 3, S - 1] = np.nan  # torch.min's index rule: the first NaN
+    with np.errstate(invalid="ignore"):
+        rdec, rfm, rsurv = oracle.acs_sweep_surv(cost)
+        rbits, rstates = oracle.traceback(rsurv, rfm)
+    ct = torch.tensor(cost, device=dev)
+    dec, fm, surv = mvn.acs_sweep_survivors(ct)
+    dec0, fm0 = mvn.acs_sweep(ct, return_final=True)
+    assert torch.equal(dec, dec0) and np.array_equal(_np(fm), _np(fm0), equal_nan=True)
+    assert np.array_equal(_np(dec), rdec) and np.array_equal(_np(fm), rfm, equal_nan=True)
+    assert surv.shape == (B, T, max(1, S // 8)) and np.array_equal(_np(surv), rsurv)
+    bits, states = mvn.traceback(surv, fm, return_states=True)
+    assert np.array_equal(_np(bits), rbits) and np.array_equal(_np(states), rstates)
+    assert int(mvn._lib.load().mvn_survivor_bytes(B, T, S)) == surv.numel()
+
+
+@pytest.mark.parametrize("L", [2, 4, 8])
+def test_va_viterbi_path_with_traceback(oracle, dev, L):
+    """VADetector.viterbi_path: the classical Viterbi sweep with survivors kept (mvn_va_decode_surv_f32) + traceback.  The running
+    decisions and final metrics it also returns are forward(y,'val')'s, the survivors are the oracle's over the same costs, and
+    the traced-back path -- which sees all L observations of a symbol, where the reference's running argmin decides from L - 1
+     -- makes fewer errors: at 12 dB and L <= 4 it recovers the transmitted word outside the block's last L symbols."""
+    S, B, T = 2 ** L, 40, 300
+    tx, y = mvn.synthetic_words(B, T, L, 12.0, 0.2, dev, seed=11 + L)
+    va = mvn.VADetector(S, L, T, 1, "ISI_AWGN", 0, False, 1, CC)
+    bits, dec, fm, surv = va.viterbi_path(y, 12.0, 0.2, return_all=True)
+    assert torch.equal(dec, va(y, "val", 12.0, 0.2))
+    pri = _np(va.compute_state_priors(mvn.estimate_channel(L, 0.2, "time_decay"))).T.copy()
+    rdec, rfm, rsurv = oracle.acs_sweep_surv(oracle.va_costs(_np(y), pri))
+    assert np.array_equal(_np(dec), rdec) and np.array_equal(_np(fm), rfm) and np.array_equal(_np(surv), rsurv)
+    assert np.array_equal(_np(bits), oracle.traceback(rsurv, rfm)[0])
+    err_path = int((bits[:, :T - L] != tx[:, :T - L]).sum().item())
+    err_running = int((dec[:, :T - L] != tx[:, :T - L]).sum().item())
+    # (8 taps of exp(-0.2 k) are heavy ISI: there the maximum-likelihood path itself errs at 12 dB, a third as often as the running argmin)
+    assert err_path <= err_running and (err_path <= 2 if L <= 4 else 2 * err_path < err_running), (err_path, err_running)
+
+
 SWEEP_VARIANTS = [(4, ""), (8, ""), (16, "rows"), (16, "lds"), (16, "quad"), (16, "inplace"), (16, "generic"), (16, "unaligned"),
                   (32, ""), (64, ""), (64, "generic"), (128, ""), (256, ""), (2, "")]
 

@@ -20,6 +20,57 @@ def test_acs_block(golden, oracle, S, B):
     assert np.array_equal(j, g[f"argj_S{S}_B{B}"])
 
 
+def _textbook_viterbi(cost):
+    """An independent NumPy Viterbi with an explicit [T, S] table of predecessor STATES and a traceback: the trellis of
+    trellis_utils.py:7-13 (state s is reached from (2s) % S and (2s+1) % S, the branch cost indexed by the predecessor), first
+    minimum on ties.  Returns the maximum-likelihood state sequence before each stage and its least-significant bits."""
+    T, S = cost.shape
+    m = np.zeros(S, np.float32)
+    pred = np.zeros((T, S), np.int64)
+    s_idx = np.arange(S)
+    for t in range(T):
+        a = (m + cost[t]).astype(np.float32)
+        c0, c1 = a[(2 * s_idx) % S], a[(2 * s_idx + 1) % S]
+        take1 = c1 < c0
+        pred[t] = np.where(take1, (2 * s_idx + 1) % S, (2 * s_idx) % S)
+        m = np.where(take1, c1, c0)
+    s = int(np.argmin(m))
+    states = np.zeros(T, np.int64)
+    for t in range(T - 1, -1, -1):
+        s = int(pred[t, s])
+        states[t] = s
+    return states, (states & 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("S", [2, 4, 8, 16, 256])
+@pytest.mark.parametrize("B", [1, 3, 64])
+def test_survivors_are_acs_blocks_indices(golden, oracle, S, B):
+    """The survivor bits of the oracle's sweep are what the reference's acs_block returns as its second value (G1 argj_*, forced
+    ties included): one stage from zero metrics over cost = in_prob + llrs is acs_block(in_prob, llrs)."""
+    g = golden("g1_acs_block")
+    cost = (g[f"in_S{S}_B{B}"] + g[f"llr_S{S}_B{B}"]).astype(np.float32).reshape(B, 1, S)
+    dec, fm, surv = oracle.acs_sweep_surv(cost)
+    assert np.array_equal(fm, g[f"out_S{S}_B{B}"])
+    bits = np.unpackbits(surv.reshape(B, -1), axis=1, bitorder="little")[:, :S]
+    assert np.array_equal(bits.astype(np.int64), g[f"argj_S{S}_B{B}"])
+
+
+@pytest.mark.parametrize("S,T", [(2, 9), (4, 33), (16, 70), (64, 40), (256, 21)])
+def test_traceback_is_the_textbook_viterbi_path(oracle, S, T):
+    """Traceback over the oracle's survivors == an independent textbook Viterbi (explicit predecessor table), and the sweep's
+    running decisions / final metrics are untouched by keeping the survivors."""
+    rng = np.random.RandomState(S + T)
+    cost = rng.normal(0, 1.5, (5, T, S)).astype(np.float32)
+    cost[3] = np.round(cost[3])  # exact ties
+    dec, fm, surv = oracle.acs_sweep_surv(cost)
+    dec0, fm0 = oracle.acs_sweep(cost)
+    assert np.array_equal(dec, dec0) and np.array_equal(fm, fm0)
+    bits, states = oracle.traceback(surv, fm)
+    for b in range(5):
+        st, bt = _textbook_viterbi(cost[b])
+        assert np.array_equal(states[b], st) and np.array_equal(bits[b], bt)
+
+
 # ---- a3-a5, a10: VA detector (va_detector.py:42-98) ---------------------------------------
 def _va_names(golden):
     return [str(n) for n in golden("g2_va")["names"]]
