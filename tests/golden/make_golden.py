@@ -456,7 +456,10 @@ def g11_meta_train_loop():
 
 
 # ----------------------------------------------------------------------------- G12, G13
-def _by_word_flow(out, tag, cls, kw, g7, blocks_frames=3, weights=None):
+ADAM_SNAPSHOT_BLOCKS = (1, 5, 6, 10, 25, 49)  # blocks at whose START the optimizer's state is recorded too (per_block runs)
+
+
+def _by_word_flow(out, tag, cls, kw, g7, blocks_frames=3, weights=None, per_block=False):
     """One run of the unmodified reference's evaluate() -> eval_by_word (trainer.py:267-354, :368-381) from the reference-trained
     weights of G7 (saved as the checkpoint load_weights reads), with every random draw it makes recorded in call order:
     torch.multinomial (select_batch, :542), torch.randint (j_hat, :337) and -- weights_init='random' -- the weights
@@ -504,11 +507,62 @@ def _by_word_flow(out, tag, cls, kw, g7, blocks_frames=3, weights=None):
         real_init()
         inits.append(np.concatenate([w.reshape(-1) for w in export_weights(tr2.detector)]))
 
+    # per_block: the state the reference holds at the START of every block -- eval_by_word calls the detector with phase 'val'
+    # exactly once per block, first thing (trainer.py:295) -- so that a replay can be re-synchronised block by block: the
+    # detector's weights (every block), the saved detector's (when they changed: trainer.py:275/:343) and, at a few blocks, the
+    # optimizer's exp_avg / exp_avg_sq / step.
+    blk_w, blk_saved_at, blk_saved, blk_adam_at, blk_adam_m, blk_adam_v, blk_adam_step = [], [], [], [], [], [], []
+    det_cls = type(tr2.detector)
+    real_forward = det_cls.forward
+
+    def flat(det):
+        return np.concatenate([w.reshape(-1) for w in export_weights(det)]).astype(np.float32)
+
+    def adam_state():
+        opt = getattr(tr2, "optimizer", None)
+        ps = list(tr2.detector.parameters())
+        m = np.concatenate([(opt.state[p_]["exp_avg"].numpy() if opt is not None and p_ in opt.state and "exp_avg" in opt.state[p_]
+                             else np.zeros(tuple(p_.shape), np.float32)).reshape(-1) for p_ in ps])
+        v = np.concatenate([(opt.state[p_]["exp_avg_sq"].numpy() if opt is not None and p_ in opt.state and "exp_avg_sq" in opt.state[p_]
+                             else np.zeros(tuple(p_.shape), np.float32)).reshape(-1) for p_ in ps])
+        step = int(opt.state[ps[0]]["step"]) if opt is not None and ps[0] in opt.state and "step" in opt.state[ps[0]] else 0
+        return m.astype(np.float32), v.astype(np.float32), step
+
+    def fspy(self_, y, phase, *a, **k):
+        if per_block and phase == "val" and self_ is tr2.detector:
+            count = len(blk_w)
+            blk_w.append(flat(tr2.detector))
+            sd_ = getattr(tr2, "saved_detector", None)
+            if sd_ is not None:
+                fs = flat(sd_)
+                if not blk_saved or not np.array_equal(fs, blk_saved[-1]):
+                    blk_saved_at.append(count)
+                    blk_saved.append(fs)
+            if count in ADAM_SNAPSHOT_BLOCKS:
+                m_, v_, st_ = adam_state()
+                blk_adam_at.append(count)
+                blk_adam_m.append(m_)
+                blk_adam_v.append(v_)
+                blk_adam_step.append(st_)
+        return real_forward(self_, y, phase, *a, **k)
+
     torch.multinomial, torch.randint, tr2.initialize_detector = mspy, rspy, ispy
+    det_cls.forward = fspy
     try:
         ser_by_word = tr2.evaluate()
     finally:
         torch.multinomial, torch.randint = real_multinomial, real_randint
+        det_cls.forward = real_forward
+    if per_block:
+        assert len(blk_w) == len(ser_by_word)
+        m_, v_, st_ = adam_state()  # ... and the optimizer's state the run ends with
+        out[f"{tag}_blk_w"] = np.stack(blk_w)
+        out[f"{tag}_blk_saved_at"] = np.array(blk_saved_at, np.int64)
+        out[f"{tag}_blk_saved"] = np.stack(blk_saved) if blk_saved else np.zeros((0, 0), np.float32)
+        out[f"{tag}_blk_adam_at"] = np.array(blk_adam_at + [len(ser_by_word)], np.int64)
+        out[f"{tag}_blk_adam_m"] = np.stack(blk_adam_m + [m_])
+        out[f"{tag}_blk_adam_v"] = np.stack(blk_adam_v + [v_])
+        out[f"{tag}_blk_adam_step"] = np.array(blk_adam_step + [st_], np.int64)
     out[f"{tag}_tx"] = tx_msg.numpy().astype(np.uint8)
     out[f"{tag}_rx"] = rx.numpy().astype(np.float32)
     out[f"{tag}_ser_by_word"] = np.asarray(ser_by_word, np.float64)
@@ -577,10 +631,10 @@ def g15_by_word_reference_defaults():
     g7 = np.load(os.path.join(HERE, "g7_by_word.npz"))
     out = {}
     _by_word_flow(out, "c2_selfsup", VNETTrainer, dict(self_supervised=True, self_supervised_iterations=200, online_meta=False,
-                                                       channel_coefficients="cost2100", fading_in_channel=False), g7, 2)
+                                                       channel_coefficients="cost2100", fading_in_channel=False), g7, 2, per_block=True)
     _by_word_flow(out, "c4_meta", METAVNETTrainer, dict(self_supervised=True, self_supervised_iterations=200, online_meta=True, MAML=True,
                                                         meta_lr=0.1, window_size=1, meta_train_iterations=20, meta_j_num=10,
-                                                        meta_subframes=5, weights_init="last_frame"), g7, 2)
+                                                        meta_subframes=5, weights_init="last_frame"), g7, 2, per_block=True)
     save("g15_by_word_reference_defaults", **out)
 
 

@@ -229,9 +229,130 @@ def test_reference_by_word_flow_other_state_counts(golden, dev, tag, route):
     assert moved > 0.005 and worst <= 5e-5
 
 
-# blocks of G15 over which every route must reproduce the reference's ser_by_word exactly (measured first differences: c2 block 34
-# on all three routes, c4 none on the HIP kernels / block 44 on stock autograd)
-G15_IDENTICAL_PREFIX = {"c2_selfsup": 30, "c4_meta": 40}
+def _flat(params):
+    return torch.cat([p.detach().reshape(-1) for p in params]).cpu().numpy()
+
+
+def _set_flat(params, flat):
+    at = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            p.copy_(torch.as_tensor(flat[at:at + n]).reshape(p.shape))
+            at += n
+    assert at == len(flat)
+
+
+# |ours - reference's| allowed in the weights one block of configs[2]'s updates leaves (<= 200 minibatch CE + Adam steps from the
+# SAME weights: different summation orders from the first matmul on); measured worst 6.7e-6 (hip) on steps that move the weights by
+# up to 0.85
+G15_BLOCK_TOL = 3e-5
+
+
+def _resynchronised_run(g, g7, tag, dev, hip):
+    """eval_by_word over the 50 recorded blocks of a G15 flow, re-synchronised on the reference after every block: returns
+    (ser_by_word, draws, per-block stats).  After block k's updates the detector's (and the saved detector's) weights are compared
+    with the state the reference held at the start of block k + 1 and then REPLACED by it, so every block is detected with, and
+    every update starts from, the reference's weights; the optimizer's moments are compared where recorded (and replaced there)."""
+    blk_w = g[f"{tag}_blk_w"]
+    w_end = np.concatenate([g[f"{tag}_w1_{i}"].reshape(-1) for i in range(6)])
+    saved_at, saved_w = g[f"{tag}_blk_saved_at"], g[f"{tag}_blk_saved"]
+    adam = {int(a): (g[f"{tag}_blk_adam_m"][i], g[f"{tag}_blk_adam_v"][i], int(g[f"{tag}_blk_adam_step"][i]))
+            for i, a in enumerate(g[f"{tag}_blk_adam_at"])}
+    assert blk_w.shape[0] == 50 and np.array_equal(blk_w[0], np.concatenate([g7[f"w{i}"].reshape(-1) for i in range(6)]))
+    tx = torch.tensor(g[f"{tag}_tx"], device=dev).float()
+    rx = torch.tensor(g[f"{tag}_rx"], device=dev)
+    kw, opt, nsym, subframes = _flow_kwargs(g, g7, tag, dev)
+    T = rx.shape[1]
+    det = mvn.VNETDetector(16, {"train": T, "val": T}).to(dev)
+    _set_flat(list(det.parameters()), blk_w[0])
+    tr = mvn.OnlineTrainer(det, 4, use_kernel=hip, **opt)
+    draws = _recorded(g, tag, dev)
+    if kw.get("online_meta"):
+        kw["meta_detector"] = mvn.META_VNETDetector(16, {"train": T, "val": T})
+    st = {"max": np.zeros(50), "median": np.zeros(50), "moved": np.zeros(50), "saved_max": np.zeros(50), "adam": []}
+
+    def observer(seen):
+        if seen["stage"] != "end":
+            return
+        k = seen["count"]
+        nxt = blk_w[k + 1] if k + 1 < 50 else w_end  # the reference's detector at the start of block k + 1
+        d = np.abs(_flat(seen["detector"].parameters()) - nxt)
+        st["max"][k], st["median"][k], st["moved"][k] = d.max(), np.median(d), np.abs(nxt - blk_w[k]).max()
+        _set_flat(list(seen["detector"].parameters()), nxt)
+        if seen["saved_detector"] is not None and len(saved_at) and k + 1 < 50:
+            j = int(np.searchsorted(saved_at, k + 1, side="right")) - 1  # the saved weights the reference held at block k + 1
+            st["saved_max"][k] = np.abs(_flat(seen["saved_detector"].parameters()) - saved_w[j]).max()
+            _set_flat(list(seen["saved_detector"].parameters()), saved_w[j])
+        if k + 1 in adam:  # the optimizer's state at the start of block k + 1 (k + 1 = 50: the state the run ends with)
+            m, v, step = adam[k + 1]
+            assert tr.step == step, (k, tr.step, step)
+            st["adam"].append((k, float(np.abs(tr.exp_avg.cpu().numpy() - m).max() / max(np.abs(m).max(), 1e-30)),
+                               float(np.abs(tr.exp_avg_sq.cpu().numpy() - v).max() / max(np.abs(v).max(), 1e-30))))
+            tr.exp_avg.copy_(torch.as_tensor(m))
+            tr.exp_avg_sq.copy_(torch.as_tensor(v))
+
+    ser = mvn.eval_by_word(det, tx, rx, 9.0, 0.2, nsym, subframes, online_trainer=tr, draws=draws, hip_meta=hip, graphed_meta=False,
+                           observer=observer, **kw)
+    return ser, draws, st
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("hip", [True, False], ids=["hip_kernels", "torch_autograd"])
+def test_config2_reference_defaults_resynchronised_block_by_block(golden, dev, hip):
+    """Golden G15 with the state the reference held at the START of every block (its detector's weights; at seven blocks the
+    optimizer's exp_avg / exp_avg_sq / step): BASELINE configs[2] at the reference's own hyperparameters, all 50 blocks, 7 800 Adam
+    steps, the replay RE-SYNCHRONISED on the reference after every block -- what a free run cannot offer once two fp32
+    trajectories have parted at a word near the decision threshold:
+      * every block is detected with the reference's weights -> ser_by_word is the reference's on ALL 50 blocks, bit for bit, and
+        with it the buffer, the blocks that train and every recorded draw (the non-lenient draws object raises otherwise);
+      * every block's 200 minibatch iterations start from the reference's weights -> what they leave is the reference's next state
+        within G15_BLOCK_TOL, block by block, and both Adam moments agree with the reference's where they were recorded."""
+    g, g7 = golden("g15_by_word_reference_defaults"), golden("g7_by_word")
+    ser, draws, st = _resynchronised_run(g, g7, "c2_selfsup", dev, hip)
+    ref = g["c2_selfsup_ser_by_word"]
+    assert np.array_equal(ser, ref), (np.flatnonzero(ser != ref), ser[ser != ref], ref[ser != ref])
+    assert draws.used_up(), (draws.m_at, len(draws.multinomial))
+    trained = int((st["moved"] > 0).sum())
+    print(f"g15 c2_selfsup {'hip' if hip else 'torch'} re-synchronised: ser identical on all 50 blocks; after each of the {trained} training "
+          f"blocks' 200 iterations the weights are within {st['max'].max():.2e} of the reference's (a block moves them by up to "
+          f"{st['moved'].max():.2f}); Adam moments (block, exp_avg, exp_avg_sq; relative to their largest entry): {st['adam']}")
+    assert trained >= 35 and st["moved"].max() > 0.3 and len(st["adam"]) == 7
+    assert st["max"].max() <= G15_BLOCK_TOL
+    assert all(em <= 1e-3 and ev <= 1e-3 for _, em, ev in st["adam"])
+
+
+@pytest.mark.timeout(900)
+def test_config4_reference_defaults_resynchronised_block_by_block(golden, dev):
+    """The same for BASELINE configs[4] (Meta-ViterbiNet at the reference's defaults: per block 200 WHOLE-WORD iterations from the
+    saved weights, every 5 blocks 20 x <= 10 second-order meta-learning steps; 9 619 Adam steps).  Detection: ser_by_word is the
+    reference's on ALL 50 blocks, every draw consumed, on the HIP kernels and on stock PyTorch autograd alike.  Updates: a block's
+    200 whole-word Adam iterations are a chaotic map at fp32 -- from the SAME weights and a fresh optimizer (block 0) stock
+    PyTorch on this GPU ends 1e-3 from the CPU reference, at later blocks single weights up to 0.3 away (they move by ~0.1 per
+    block) -- so no implementation can be held to a rounding-sized bound per block here; what is asserted is that the HIP kernels
+    stand where stock PyTorch-GPU stands: per block the median |weight - reference's| of the two routes within a factor of 3 of
+    each other in the geometric mean over the training blocks, and below 1e-3 on every block (measured: medians 1e-8 ... 8e-4, the
+    ratio's geometric mean 1.1).  The iteration-by-iteration statement (every Adam step of this flow against torch and a float64
+    referee) is tests/test_gpu_replay.py."""
+    g, g7 = golden("g15_by_word_reference_defaults"), golden("g7_by_word")
+    ref = g["c4_meta_ser_by_word"]
+    stats = {}
+    for hip in (True, False):
+        ser, draws, st = _resynchronised_run(g, g7, "c4_meta", dev, hip)
+        assert np.array_equal(ser, ref), (hip, np.flatnonzero(ser != ref), ser[ser != ref], ref[ser != ref])
+        assert draws.used_up(), (draws.r_at, len(draws.randint))
+        stats[hip] = st
+    both = (stats[True]["median"] > 0) & (stats[False]["median"] > 0)
+    ratio = stats[True]["median"][both] / stats[False]["median"][both]
+    geo = float(np.exp(np.mean(np.log(ratio))))
+    print(f"g15 c4_meta re-synchronised: ser identical on all 50 blocks on both routes; per-block median |w - reference's| hip "
+          f"{stats[True]['median'][both].min():.1e} ... {stats[True]['median'].max():.1e}, stock autograd {stats[False]['median'][both].min():.1e} ... "
+          f"{stats[False]['median'].max():.1e}; hip / autograd geometric mean {geo:.2f} over {int(both.sum())} training blocks (range "
+          f"{ratio.min():.2f} ... {ratio.max():.2f}); worst single weight hip {stats[True]['max'].max():.2f}, autograd {stats[False]['max'].max():.2f}; "
+          f"block 0 (same weights, fresh optimizer): hip {stats[True]['max'][0]:.1e}, autograd {stats[False]['max'][0]:.1e}")
+    assert int(both.sum()) >= 35
+    assert 1 / 3 <= geo <= 3
+    assert stats[True]["median"].max() <= 1e-3 and stats[False]["median"].max() <= 1e-3
 
 
 @pytest.mark.timeout(900)
@@ -242,13 +363,13 @@ def test_reference_by_word_flow_at_reference_defaults(golden, dev, tag, route):
     configs[4] (Meta-ViterbiNet: 200 whole-word iterations per block from the saved weights, every 5 blocks 20 x <= 10 second-order
     meta-learning steps) at the reference's OWN hyperparameters, 50 blocks at 9 dB, run by the unmodified reference with every draw
     recorded -- 7 800 and ~11 000 Adam steps on weights that move by 0.8.
-    A free run of that length is where fp32 trajectories of two implementations part (tests/test_gpu_replay.py walks the same
-    flows step by step for that reason): the weights end 0.1 apart, and at some block a word near the decision threshold decodes
-    with one or two bit errors more or less -- after which the runs also train on different blocks.  Stock PyTorch on this GPU
-    ('torch_autograd': torch's own autograd and Adam, no kernel of this repo in the training) parts from the CPU reference the
-    same way, at the same or an earlier block.  Asserted: ser_by_word identical over the first G15_IDENTICAL_PREFIX blocks
-    (30 / 40 of 50; ~6 000 Adam steps; measured 34-35 / 44-50), the first differing block within two bit errors, the mean ser
-    of the 50 blocks within half of the reference's."""
+    This is the FREE run (no re-synchronisation: test_reference_defaults_resynchronised_block_by_block above is the parity
+    statement over all 50 blocks).  A free run of that length is where fp32 trajectories of two implementations part: the weights
+    end 0.1 apart, and at some block a word near the decision threshold decodes with one or two bit errors more or less -- after
+    which the runs also train on different blocks.  Stock PyTorch on this GPU ('torch_autograd': torch's own autograd and Adam,
+    no kernel of this repo in the training) parts from the CPU reference the same way, at the same or an earlier block (measured
+    first differing block: 34-35 of 50 for configs[2], 44-50 for configs[4]).  Asserted here: the first differing block (if
+    any) within two bit errors, the mean ser of the 50 blocks within half of the reference's; the block is printed."""
     from meta_viterbinet_amd.trials import TrialBank, eval_by_word_batched
 
     g, g7 = golden("g15_by_word_reference_defaults"), golden("g7_by_word")
@@ -273,7 +394,6 @@ def test_reference_by_word_flow_at_reference_defaults(golden, dev, tag, route):
     print(f"g15 {tag} {route}: ser identical on the first {first} of 50 blocks"
           + (f" (block {first}: {ser[first]:.4f} vs the reference's {ref[first]:.4f})" if first < 50 else "")
           + f"; mean ser {ser.mean():.5f} vs {ref.mean():.5f}; weights moved {moved:.3f}, end {worst:.2e} from the reference's")
-    assert first >= G15_IDENTICAL_PREFIX[tag]
     if first < 50:
         assert abs(ser[first] - ref[first]) <= 2.5 / 120
     assert abs(ser.mean() - ref.mean()) <= 0.5 * ref.mean()  # (50 blocks: a handful of bit errors either way after the runs part)

@@ -329,10 +329,10 @@ def _report(name, out, ser, steps):
 @pytest.mark.timeout(1700)
 def test_config2_self_supervised_replayed_iteration_by_iteration(golden, dev):
     """BASELINE configs[2] with updates: ViterbiNet over the COST2100 taps, 300 blocks, 200 CE + Adam minibatch iterations
-    (online_train_kernel) after every qualifying block; every 2nd block's 200 iterations walked one by one."""
+    (online_train_kernel) after every qualifying block; EVERY block's 200 iterations walked one by one (MVN_REPLAY_STRIDE=1)."""
     g7 = golden("g7_by_word")
     msg, rx = _words(dev, "cost2100", 10.0, 5)
-    stride = int(os.environ.get("MVN_REPLAY_STRIDE", "2"))
+    stride = int(os.environ.get("MVN_REPLAY_STRIDE", "1"))
     out, ser, steps = _replay(dev, [g7[f"w{i}"] for i in range(6)], msg, rx, dict(self_supervised=True), 200, stride=stride)
     _report("configs[2]", out, ser, steps)
     assert out["segments"] >= 150 and steps == 200 * out["segments"] and out["iterations"] == 200 * out["walked"]
