@@ -202,7 +202,13 @@ int mvn_count_errors(const float *dec, int64_t dec_ld, const float *tx, int64_t 
  *   W1..b3: parameters, updated in place; adam_m/adam_v: [P] exp_avg / exp_avg_sq in parameter order
  *   (P = 250 + 50*100 + 51*S), updated in place; step0 = Adam steps already taken;
  *   loss_out [n_iter] or NULL.  S <= 32.  fp32; agrees with torch autograd + Adam to rounding, not bitwise.
+ * The trainer's other optimizers (deep_learning_setup, trainer.py:163-175) ride on the same arguments: beta1 = MVN_BETA1_RMSPROP
+ * runs torch.optim.RMSprop's update (alpha = beta2, eps; square average in adam_v, adam_m untouched; torch's defaults: no
+ * momentum, not centered), beta1 = MVN_BETA1_SGD torch.optim.SGD's (p -= lr g; adam_m / adam_v untouched).  The same holds for
+ * the _ws_ and _trials_ forms of this call; the meta-learning calls below take Adam only.
  */
+#define MVN_BETA1_RMSPROP (-1.0f)
+#define MVN_BETA1_SGD (-2.0f)
 int mvn_vnet_online_train_f32(const float *y, const int32_t *labels, int32_t T, const int32_t *batch_idx, int32_t M,
                               int32_t n_iter, float *W1, float *b1, float *W2, float *b2, float *W3, float *b3,
                               float *adam_m, float *adam_v, int64_t step0, float lr, float beta1, float beta2, float eps,

@@ -17,9 +17,10 @@ class OnlineTrainer:
             raise NotImplementedError("No such optimizer implemented!!!")
         self.detector = detector
         self.optimizer_type = optimizer_type
-        # False: online_training on stock PyTorch autograd (the cross-check of the kernel).  The one-launch kernels implement
-        # the reference's default, Adam (config.yaml:35); RMSprop and SGD run on the autograd route.
-        self.use_kernel = use_kernel and optimizer_type == "Adam"
+        # False: online_training on stock PyTorch autograd (the cross-check of the kernel).  The one-launch online-training kernels
+        # implement all three optimizers of deep_learning_setup (Adam, the reference's default, config.yaml:35; RMSprop and SGD with
+        # torch's defaults); the meta-learning kernel implements Adam (harness.eval_by_word takes autograd for the others).
+        self.use_kernel = use_kernel
         self.memory_length = memory_length
         self.lr, self.betas, self.eps = lr, betas, eps
         self.train_minibatch_size = train_minibatch_size
@@ -35,6 +36,15 @@ class OnlineTrainer:
         self.sync_words = torch.zeros(2, dtype=torch.int32, device=dev) if dev.type == "cuda" else None
         self.status = self.sync_words[1:2] if dev.type == "cuda" else None
         self._unchecked = False
+
+    def kernel_optimizer_args(self):
+        """(beta1, beta2, eps) as the training kernels take them: Adam's own; beta1 = MVN_BETA1_RMSPROP (-1) with alpha = 0.99 and
+        eps = 1e-8 (torch.optim.RMSprop's defaults, as deep_learning_setup builds it); beta1 = MVN_BETA1_SGD (-2)."""
+        if self.optimizer_type == "RMSprop":
+            return -1.0, 0.99, 1e-8
+        if self.optimizer_type == "SGD":
+            return -2.0, 0.0, 0.0
+        return self.betas[0], self.betas[1], self.eps
 
     def reset_state(self):
         """A fresh optimizer, like the deep_learning_setup() call of meta_weights_init('random') (trainer.py:356-359)."""
@@ -120,6 +130,8 @@ class OnlineTrainer:
         reference's fancy indexing).  Uses and advances the same Adam state as online_training.
         labels: int32 [Nw, T], the trellis states of tx_words when the caller already has them (the block-step kernel writes them
         next to the word it buffers); None: calculate_states(tx_words)."""
+        if self.optimizer_type != "Adam":  # (harness.eval_by_word runs the meta-learning updates of the other optimizers on autograd)
+            raise NotImplementedError("the meta-learning kernel implements Adam; use meta.meta_train_loop for RMSprop / SGD")
         p = self.params
         dev = p[0].device
         _lib.require_gpu_tensor(rx_words, "rx_words")
@@ -195,11 +207,12 @@ class OnlineTrainer:
         loss = torch.empty(iterations, dtype=torch.float32, device=dev) if return_loss else None
         S = p[5].numel()
         ws = self._workspace(S, dev)
+        b1, b2, eps = self.kernel_optimizer_args()
         with torch.cuda.device(dev):
             rc = _lib.load().mvn_vnet_online_train_ws_f32(_lib.ptr(y), _lib.ptr(labels), T, _lib.ptr(idx), M, iterations,
                                                           *[_lib.ptr(t.data) for t in p], _lib.ptr(self.exp_avg),
-                                                          _lib.ptr(self.exp_avg_sq), self.step, self.lr, self.betas[0],
-                                                          self.betas[1], self.eps, _lib.ptr(loss), S, _lib.ptr(ws), ws.numel(),
+                                                          _lib.ptr(self.exp_avg_sq), self.step, self.lr, b1, b2, eps,
+                                                          _lib.ptr(loss), S, _lib.ptr(ws), ws.numel(),
                                                           _lib.ptr(self.status), _lib.current_stream(dev))
         _lib.check(rc, "mvn_vnet_online_train_ws_f32")
         self._unchecked = True

@@ -184,8 +184,7 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
                          weights_init: str = "last_frame", meta_training_weights=None, record: Optional[dict] = None,
                          cohorts: int = 1, initial_buffer=None) -> np.ndarray:
     """R trials of harness.eval_by_word (= Trainer.eval_by_word, trainer.py:267-354) at once, with the reference's switches:
-    buffer_empty True / False, weights_init last_frame / random / meta_training, Adam on the GPU kernels (RMSprop / SGD: see
-    below).
+    buffer_empty True / False, weights_init last_frame / random / meta_training, Adam / RMSprop / SGD.
     tx [R, N, K] message bits, rx [R, N, K + 8 n_symbols] received words (trial r = row r, its own SNR / channel / seed);
     bank: the trials' weights and optimizer state (updated in place); draws[r]: trial r's TrialDraws.
     Returns ser_by_word [R, N] (0 for pilots), row r equal to eval_by_word(..., draws=draws[r]) run alone.
@@ -194,8 +193,9 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
     (trainer.py:278-286) -- every trial's buffer starts with these W0 words and stays W0 long, each qualifying block pushing the
     oldest out (:325-328).  weights_init='random' (meta_weights_init, :356-359): before every meta-learning update the trial's
     weights are re-initialised from ITS OWN stream (TrialDraws.init_weights) and its optimizer state reset.
-    bank.optimizer_type 'RMSprop' / 'SGD' (deep_learning_setup, :163-175): the training kernels implement Adam, the reference's
-    default; the other two optimizers run trial after trial through harness.eval_by_word on stock autograd -- same results as
+    bank.optimizer_type 'RMSprop' / 'SGD' (deep_learning_setup, :163-175): the online-training kernel implements them next to
+    Adam, the reference's default (round 5); the meta-learning kernel implements Adam, so a run with online_meta and another
+    optimizer goes trial after trial through harness.eval_by_word (its meta-learning updates on stock autograd) -- same results as
     calling it yourself, no batching.  So do detectors with another state count than 16 (the one-launch block step and its
     R-word form serve 16 states): trial after trial through harness.eval_by_word, there on the run-time-n_states training kernels.
     cohorts > 1: the trials are split into that many groups that step ALTERNATELY on the same stream: while the GPU works
@@ -215,7 +215,7 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
         if ib[0].shape != ib[1].shape or ib[0].shape[0] != R or ib[0].shape[2] != rx.shape[2]:
             raise ValueError("initial_buffer = (tx_codewords, rx_words), each [W0, T] or [R, W0, T]")
         initial_buffer = ib
-    if bank.optimizer_type != "Adam" or bank.n_states != 16:
+    if (bank.optimizer_type != "Adam" and online_meta) or bank.n_states != 16:
         return _one_trial_at_a_time(bank, tx, rx, n_symbols, subframes_in_frame, draws, ser_by_word, record, initial_buffer,
                                     dict(self_supervised=self_supervised, self_supervised_iterations=self_supervised_iterations,
                                          ser_thresh=ser_thresh, online_meta=online_meta, meta_lr=meta_lr, MAML=MAML, window_size=window_size,
@@ -248,8 +248,8 @@ def eval_by_word_batched(bank: TrialBank, tx: torch.Tensor, rx: torch.Tensor, n_
 
 def _one_trial_at_a_time(bank, tx, rx, n_symbols, subframes_in_frame, draws, ser_by_word, record, initial_buffer, kw,
                          train_minibatch_size):
-    """The trials of a bank the lock-step engine does not serve -- an optimizer the training kernels do not implement (RMSprop,
-    SGD: stock autograd) or another state count than 16 (no R-word block step) -- one after the other through harness.eval_by_word;
+    """The trials of a bank the lock-step engine does not serve -- meta-learning with an optimizer its kernel does not implement
+    (RMSprop, SGD) or another state count than 16 (no R-word block step) -- one after the other through harness.eval_by_word;
     weights, saved weights, optimizer state and step counts go back into the bank."""
     from .detectors import META_VNETDetector, VNETDetector
     from .harness import eval_by_word
@@ -307,6 +307,11 @@ def _cohort_steps(bank, tx, rx, n_symbols, subframes_in_frame, draws, ser_by_wor
     tx = _lib.f32c(tx).to(dev)
     S, W = bank.n_states, window_size
     b1, b2 = bank.betas
+    eps_k = bank.eps
+    if bank.optimizer_type == "RMSprop":  # the online-training kernel's encoding (include/mvn.h: MVN_BETA1_RMSPROP, alpha = beta2)
+        b1, b2, eps_k = -1.0, 0.99, 1e-8
+    elif bank.optimizer_type == "SGD":
+        b1, b2, eps_k = -2.0, 0.0, 0.0
     full_word = meta_style_online_training
     M = 0 if full_word else train_minibatch_size
 
@@ -446,7 +451,7 @@ def _cohort_steps(bank, tx, rx, n_symbols, subframes_in_frame, draws, ser_by_wor
             off = R * TRIAL_DTYPE.itemsize
             desc.dev[off:off + len(act) * TRIAL_DTYPE.itemsize].copy_(desc.host[off:off + len(act) * TRIAL_DTYPE.itemsize],
                                                                       non_blocking=True)
-            rc = lib.mvn_vnet_online_train_trials_f32(desc_onl_ptr, len(act), T, M, bank.lr, b1, b2, bank.eps, S,
+            rc = lib.mvn_vnet_online_train_trials_f32(desc_onl_ptr, len(act), T, M, bank.lr, b1, b2, eps_k, S,
                                                       _lib.ptr(ws), ws_bytes, stream)
             _lib.check(rc, "mvn_vnet_online_train_trials_f32")
     sync_host.copy_(sync_dev, non_blocking=True)

@@ -770,7 +770,7 @@ def test_reference_word_stream_replays_the_dataset(golden, dev, name):
 
 
 # ---------------------------------------------------------------- next #3: online (self-supervised) training in one launch
-def _torch_online_ref(w, y, labels, idx, lr, n_iter, full_word=False):
+def _torch_online_ref(w, y, labels, idx, lr, n_iter, full_word=False, optimizer="Adam"):
     """The reference's arithmetic for run_train_loop (trainer.py:492-505): torch autograd, CrossEntropyLoss(mean),
     torch.optim.Adam, on CPU in fp32.  (A torch reference is the right oracle for this floating-point kernel.)"""
     net = torch.nn.Sequential(torch.nn.Linear(1, 100), torch.nn.Sigmoid(), torch.nn.Linear(100, 50), torch.nn.ReLU(),
@@ -778,7 +778,7 @@ def _torch_online_ref(w, y, labels, idx, lr, n_iter, full_word=False):
     with torch.no_grad():
         for p, a in zip(net.parameters(), w):
             p.copy_(torch.tensor(a))
-    opt = torch.optim.Adam(net.parameters(), lr=lr)
+    opt = getattr(torch.optim, optimizer)(net.parameters(), lr=lr)  # (deep_learning_setup, trainer.py:163-175: torch's defaults)
     crit = torch.nn.CrossEntropyLoss()
     losses = []
     yt, lt = torch.tensor(y).reshape(-1, 1), torch.tensor(labels).long()
@@ -838,6 +838,80 @@ def test_online_training_vs_torch(dev, n_iter, full_word, M):
     assert np.allclose(loss, ref_loss, rtol=2e-4, atol=1e-6)
     for i, p in enumerate(det.net.parameters()):
         assert np.all(np.abs(_np(p) - ref_w[i]) <= 2e-5 + 1e-3 * np.abs(ref_w[i])), i
+
+
+@pytest.mark.parametrize("optimizer,lr", [("RMSprop", 1e-3), ("SGD", 0.05)])
+@pytest.mark.parametrize("n_iter,full_word,form", [(12, False, "one"), (5, True, "chunked"), (5, True, "one"), (9, False, "trials")])
+def test_online_training_other_optimizers_vs_torch(dev, monkeypatch, optimizer, lr, n_iter, full_word, form):
+    """The trainer's other two optimizers (deep_learning_setup, trainer.py:163-175: torch.optim.RMSprop / SGD, torch's defaults)
+    inside the online-training kernels (beta1 = MVN_BETA1_RMSPROP / MVN_BETA1_SGD): against torch autograd + torch.optim on the
+    same word and draws, on the one-workgroup kernel, its one-workgroup-per-chunk form and the trial-batched entry point, the
+    optimizer state carried over two calls.  Tolerance as for Adam (reduction order differs from torch's)."""
+    S, T, L = 16, 136, 4
+    rng = np.random.RandomState(n_iter + len(optimizer))
+    w = _rand_weights(S, rng)
+    tx = rng.randint(0, 2, (1, T)).astype(np.float32)
+    y = rng.normal(0, 1.5, (1, T)).astype(np.float32)
+    labels = mvn.calculate_states(L, torch.tensor(tx)).numpy()
+    idx = np.stack([rng.choice(np.arange(1, T), 32, replace=False) for _ in range(n_iter)]).astype(np.int32)
+    ref_w, ref_loss = _torch_online_ref(w, y[0], labels, idx, lr, n_iter, full_word, optimizer)
+    n1 = n_iter // 2
+    if form == "trials":
+        from meta_viterbinet_amd.trials import TrialBank, TrialDraws, eval_by_word_batched  # noqa: F401
+
+        bank = TrialBank([w, w], S, L, dev, lr=lr, optimizer_type=optimizer)
+        tr_mod = __import__("meta_viterbinet_amd.trials", fromlist=["TRIAL_DTYPE"])
+        lib = mvn._lib.load()
+        yt = torch.tensor(y, device=dev).repeat(2, 1).contiguous()
+        lab = torch.tensor(labels, device=dev).to(torch.int32).reshape(1, T).repeat(2, 1).contiguous()
+        bidx = torch.tensor(idx, device=dev).unsqueeze(0).repeat(2, 1, 1).contiguous()
+        th = bank.pointers(bank.theta)
+        b1, b2, eps = {"RMSprop": (-1.0, 0.99, 1e-8), "SGD": (-2.0, 0.0, 0.0)}[optimizer]
+        for lo, n in ((0, n1), (n1, n_iter - n1)):
+            d = np.zeros(2, dtype=tr_mod.TRIAL_DTYPE)
+            for r in range(2):
+                d[r]["y"], d[r]["labels"] = yt[r].data_ptr(), lab[r].data_ptr()
+                d[r]["idx"] = bidx[r, lo:].data_ptr()
+                d[r]["w_in"], d[r]["w_out"] = th[r], th[r]
+                d[r]["adam_m"], d[r]["adam_v"] = bank.exp_avg[r].data_ptr(), bank.exp_avg_sq[r].data_ptr()
+                d[r]["b1pow"], d[r]["b2pow"] = 1.0, 1.0
+                d[r]["n"] = n
+            dd = torch.from_numpy(d.view(np.uint8)).to(dev)
+            rc = lib.mvn_vnet_online_train_trials_f32(mvn._lib.ptr(dd), 2, T, 32, lr, b1, b2, eps, S, None, 0, mvn._lib.current_stream(dev))
+            assert rc == 0
+        torch.cuda.synchronize()
+        got = [_np(t) for t in bank.weights(0)]
+        assert torch.equal(bank.theta[0], bank.theta[1])
+        if optimizer == "SGD":
+            assert float(bank.exp_avg_sq.abs().max()) == 0.0 and float(bank.exp_avg.abs().max()) == 0.0
+        else:
+            assert float(bank.exp_avg_sq.abs().max()) > 0.0 and float(bank.exp_avg.abs().max()) == 0.0
+    else:
+        monkeypatch.setenv("MVN_TRAIN_GROUPS", "1" if form == "chunked" else "0")
+        det = _vnet_with(w, S, T, dev)
+        tr = mvn.OnlineTrainer(det, L, lr=lr, optimizer_type=optimizer)
+        assert tr.use_kernel
+        txt, yt = torch.tensor(tx, device=dev), torch.tensor(y, device=dev)
+        l1 = tr.online_training(txt, yt, iterations=n1, batch_idx=torch.tensor(idx[:n1], device=dev), full_word=full_word, return_loss=True)
+        l2 = tr.online_training(txt, yt, iterations=n_iter - n1, batch_idx=torch.tensor(idx[n1:], device=dev), full_word=full_word,
+                                return_loss=True)
+        tr.check_status()
+        loss = np.concatenate([_np(l1), _np(l2)])
+        assert np.allclose(loss, ref_loss, rtol=2e-4, atol=1e-6)
+        got = [_np(p) for p in det.net.parameters()]
+        # the same two calls on the autograd route of the same trainer class (OnlineTrainer.optimizer_step)
+        det2 = _vnet_with(w, S, T, dev)
+        tr2 = mvn.OnlineTrainer(det2, L, lr=lr, optimizer_type=optimizer, use_kernel=False)
+        tr2.online_training(txt, yt, iterations=n1, batch_idx=torch.tensor(idx[:n1], device=dev), full_word=full_word)
+        tr2.online_training(txt, yt, iterations=n_iter - n1, batch_idx=torch.tensor(idx[n1:], device=dev), full_word=full_word)
+        for a, p2 in zip(got, det2.net.parameters()):
+            assert np.all(np.abs(a - _np(p2)) <= 2e-5 + 1e-3 * np.abs(a))
+        if optimizer == "RMSprop":
+            assert np.allclose(_np(tr.exp_avg_sq), _np(tr2.exp_avg_sq), rtol=2e-3, atol=1e-10)
+    moved = max(float(np.abs(got[i] - w[i]).max()) for i in range(6))
+    assert moved > 1e-4
+    for i in range(6):
+        assert np.all(np.abs(got[i] - ref_w[i]) <= 2e-5 + 1e-3 * np.abs(ref_w[i])), i
 
 
 def test_online_training_draws_like_select_batch(dev):
