@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from trial_setup import L, T, dev, mvn, w  # noqa: E402
 from meta_viterbinet_amd import trials as tr_mod  # noqa: E402
 
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 3
 lib = mvn._lib.load()
 S, NW = 16, 12
 gen = torch.Generator(device=dev).manual_seed(1)
@@ -68,7 +68,7 @@ def run(kind, R, n, M=0, second_order=1):
         launch()
     b.record()
     b.synchronize()
-    assert int(status.abs().sum()) == 0 and bool(torch.isfinite(bank.theta).all())
+    assert "--no-check" in sys.argv or (int(status.abs().sum()) == 0 and bool(torch.isfinite(bank.theta).all()))
     return a.elapsed_time(b) / reps, name.value.decode()
 
 
