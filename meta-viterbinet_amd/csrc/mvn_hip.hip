@@ -593,12 +593,22 @@ bool fused_ip_selected(int S) {
     return S <= 64;
 }
 
-// Small batches take the cooperative kernel (vnet16_coop.inc); MVN_COOP=0|1 pins the choice (A/B runs, tests).
-bool coop_selected(int64_t B, int T) {
+// The cooperative kernel (vnet16_coop.inc: a 16-wave workgroup per block, one wave sweeping all T steps after the others' MLP
+// tiles) against the dealt kernel run with one 8-wave ring per block (its eight waves sweep their units as they finish them):
+// measured at 1 ... 768 blocks x 64 ... 1000 symbols (tools/time_coop_vs_dealt.py, profiles/r05_time_coop_vs_dealt.txt) the
+// cooperative kernel wins where a block is SHORT and the batch fits one workgroup per CU -- T <= 384 up to CUs blocks (0.68-0.98 x
+// the dealt kernel's time; T = 136, the by-word evaluation's call: 0.84), T <= 128 up to 2 CUs -- and loses everywhere else
+// (1.05-1.7 x: a long block's sweep by one wave is a serial tail, and 16-wave workgroups run one per CU at a time).
+// MVN_COOP=0|1 pins the choice (A/B runs, tests).  with_workspace = false: the caller gave no hand-off lines, the dealt kernel is
+// not available and the cooperative one keeps its round-4 range (up to kCoopMaxBlocks blocks) against the one-wave-per-block kernel.
+bool coop_selected(int64_t B, int T, bool with_workspace = true) {
     if (T > kCoopMaxT) return false;
     const char e = sw(SW_COOP);
     if (e == '0' || e == '1') return e == '1';
-    return B <= kCoopMaxBlocks;
+    if (!with_workspace || sw(SW_DEALT) == '0') return B <= kCoopMaxBlocks;
+    const int n_cu = current_device_cus();
+    const int64_t cus = n_cu > 0 ? n_cu : 256;
+    return (B <= cus && T <= 384) || (B <= 2 * cus && T <= 128);
 }
 
 // MVN_FUSEDN=2|4 pins the tiles per super-tile of the fused kernel (vnet16_fusedn.inc); default 2 (6 waves/SIMD).
@@ -720,7 +730,10 @@ int launch_vnet16_fused(const float *y, int64_t y_ld, const float *W1, const flo
                         float *final_metric, int64_t B, int T, const float *tx, int64_t tx_ld, int K,
                         const unsigned char *row_mask, unsigned long long *counters, hipStream_t st, void *workspace = nullptr,
                         size_t workspace_bytes = 0) {
-    if (coop_selected(B, T)) {  // small batch: a 16-wave workgroup per block (MLP tiles in parallel, one sweeping wave)
+    const DealtPlan dplan = dealt_plan(B, T);
+    const bool can_deal = dplan.groups && workspace && workspace_bytes >= dealt_workspace_bytes(dplan.rings()) &&
+                          !(reinterpret_cast<uintptr_t>(workspace) & 127);
+    if (coop_selected(B, T, can_deal)) {  // small batch: a 16-wave workgroup per block (MLP tiles in parallel, one sweeping wave)
         const size_t dyn = (size_t)((T + 15) / 16) * 1024;
         const void *fn = logits_out ? (const void *)vnet16_coop_kernel<true> : (const void *)vnet16_coop_kernel<false>;
         if (int e = ensure_dynamic_lds(fn, (size_t)(kCoopMaxT / 16 * 1024))) return e;
@@ -733,8 +746,8 @@ int launch_vnet16_fused(const float *y, int64_t y_ld, const float *W1, const flo
         if (tx) hipLaunchKernelGGL(count_totals_kernel, dim3(1), dim3(1024), 0, st, row_mask, B, K, counters);
         return (int)hipGetLastError();
     }
-    if (const DealtPlan dp = dealt_plan(B, T); dp.groups && workspace && workspace_bytes >= dealt_workspace_bytes(dp.rings()) &&
-                                               !(reinterpret_cast<uintptr_t>(workspace) & 127)) {
+    if (can_deal) {
+        const DealtPlan dp = dplan;
         const unsigned long long nonce = dealt_nonce();  // what a SET hand-off flag holds in this launch: nothing to clear
         if (logits_out)
             hipLaunchKernelGGL((vnet16_dealt_kernel<true>), dim3((unsigned)dp.groups), dim3(64 * kDealtWaves), 0, st, y, y_ld, W1, b1, W2, b2,
