@@ -674,7 +674,8 @@ def main():
         acs_gbps = ACS_BYTES_PER_SYMBOL * B * T / (ms_acs * 1e-3) / 1e9
         acs_kernel = kernel_name(lib.mvn_acs_sweep_kernel_name, mvn._lib.ptr(cost), mvn._lib.ptr(dec), T, B, T, S)
         fused_kernel = kernel_name(lib.mvn_vnet_decode_kernel_name, B, T, S, 0)
-        traffic_fused, traffic_fused_src = profiled("traffic.json", fused_kernel, "bytes_per_launch", (B, T, S))
+        # (rocprofv3 names the kernel without the launcher's " rings of N" suffix)
+        traffic_fused, traffic_fused_src = profiled("traffic.json", fused_kernel.split(" rings of")[0], "bytes_per_launch", (B, T, S))
         traffic_acs, traffic_acs_src = profiled("traffic.json", acs_kernel, "bytes_per_launch", (B, T, S))
         out = {
             "metric": "decoded symbols/sec, ViterbiNet L=4 ISI (16 states)",

@@ -1085,7 +1085,7 @@ def test_integration_md_ctypes_stub(oracle, dev):
     ns = {"nn": nn}
     exec(compile(block.replace("    ...\n", init, 1), "INTEGRATION.md", "exec"), ns)
     rng = np.random.RandomState(8)
-    for S, B, T in ((16, 9, 77), (4, 5, 40)):
+    for S, B, T in ((16, 9, 77), (4, 5, 40), (16, 900, 40)):  # (the last: a batch the dealt kernel takes, with the stub's workspace)
         w = _rand_weights(S, rng)
         det = ns["VNETDetector"](S, {"train": T, "val": T}).to(dev)
         with torch.no_grad():

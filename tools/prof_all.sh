@@ -1,27 +1,27 @@
-# Round-end measurement pass (one gpurun call): PMC passes, bench line, kernel traces, timing tools -> gpurun_out/r04p/
+# Round-end measurement pass (one gpurun call): PMC passes, bench line, kernel traces, timing tools -> gpurun_out/r05p/
 # (copy what is to be judged into profiles/ afterwards: tools/collect_profiles.sh).
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r04p
+O=$R/gpurun_out/r05p
 mkdir -p $O
 # whatever happens, the raw rocprofv3 directories do not travel home (gpurun_out/ is merged back only below 64 MiB)
 trap 'rm -rf $O/kt $O/kh $O/pmc/FETCH_SIZE $O/pmc/WRITE_SIZE $O/pmc/TCC* $O/pmc/SQ* $O/pmc_train/pass*/ $O/pmc_head*/pass*/ $O/pmc_va256/pass*/' EXIT
 # the counter passes first: bench.py reads profiles/traffic.json, valu_insts.json and train_pmc.json and ignores them unless they
 # carry the sha of the kernel sources it runs (they are copied into profiles/ here, on the box; copy them again from gpurun_out/ at home)
-cd $R && bash tools/pmc_traffic.sh gpurun_out/r04p/pmc > $O/pmc.log 2>&1
+cd $R && bash tools/pmc_traffic.sh gpurun_out/r05p/pmc > $O/pmc.log 2>&1
 cp $O/pmc/traffic.json $O/pmc/valu_insts.json $R/profiles/
 echo pmc done
-bash tools/pmc_sq.sh gpurun_out/r04p/pmc_train tools/prof_train_kernels.py 2 > $O/pmc_train.log 2>&1
-python3 tools/pmc_dispatch_table.py gpurun_out/r04p/pmc_train train > $O/train_pmc_table.csv
+bash tools/pmc_sq.sh gpurun_out/r05p/pmc_train tools/prof_train_kernels.py 2 > $O/pmc_train.log 2>&1
+python3 tools/pmc_dispatch_table.py gpurun_out/r05p/pmc_train train > $O/train_pmc_table.csv
 python3 tools/pmc_train_json.py $O/train_pmc_table.csv 2 $O/train_pmc.json > /dev/null
 cp $O/train_pmc.json $R/profiles/
 echo pmc train done
 for B in 10000 40960; do
-  bash tools/pmc_sq.sh gpurun_out/r04p/pmc_head$B tools/prof_headline.py $B 5 > $O/pmc_head$B.log 2>&1
-  python3 tools/pmc_dispatch_table.py gpurun_out/r04p/pmc_head$B fusedn | (read h; echo "$h"; tail -5) > $O/headline_pmc_$B.csv
+  bash tools/pmc_sq.sh gpurun_out/r05p/pmc_head$B tools/prof_headline.py $B 5 > $O/pmc_head$B.log 2>&1
+  python3 tools/pmc_dispatch_table.py gpurun_out/r05p/pmc_head$B dealt | (read h; echo "$h"; tail -5) > $O/headline_pmc_$B.csv
 done
-bash tools/pmc_sq.sh gpurun_out/r04p/pmc_va256 tools/prof_va256.py 125000 3 > $O/pmc_va256.log 2>&1
-python3 tools/pmc_dispatch_table.py gpurun_out/r04p/pmc_va256 va256_wave | (read h; echo "$h"; tail -3) > $O/va256_pmc.csv
+bash tools/pmc_sq.sh gpurun_out/r05p/pmc_va256 tools/prof_va256.py 125000 3 > $O/pmc_va256.log 2>&1
+python3 tools/pmc_dispatch_table.py gpurun_out/r05p/pmc_va256 va256_wave | (read h; echo "$h"; tail -3) > $O/va256_pmc.csv
 echo pmc headline + va256 done
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
