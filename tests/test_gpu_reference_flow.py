@@ -174,7 +174,7 @@ G13 = ["fomaml", "window", "random", "metatrain", "support2", "rmsprop", "sgd"]
 def test_reference_by_word_switches(golden, dev, tag, hip):
     """The reference's remaining eval_by_word switches, one recorded 50-block run each (golden G13): first-order meta-learning,
     the pre-filled fixed-length buffer, meta_weights_init 'random' / 'meta_training', two support words, RMSprop, SGD (the last
-    two train on autograd in either parametrisation: the kernels implement Adam)."""
+    two: in the online-training kernel since round 5, hip parametrisation; on torch.optim in the other)."""
     g, g7 = golden("g13_by_word_switches"), golden("g7_by_word")
     ser, draws, w, saved = _run(g, g7, tag, dev, hip)
     ref = g[f"{tag}_ser_by_word"]
@@ -426,8 +426,8 @@ class RecordedTableDraws(RecordedDraws):
 
 @pytest.mark.parametrize("tag", ["selfsup", "meta"] + G13)
 def test_reference_by_word_flow_batched_trials(golden, dev, tag):
-    """The same reference runs as R = 3 identical trials of eval_by_word_batched (the trial-batched training kernels; RMSprop / SGD:
-    its trial-after-trial autograd route): every row must reproduce the reference's ser_by_word and end on its weights."""
+    """The same reference runs as R = 3 identical trials of eval_by_word_batched (the trial-batched training kernels, RMSprop / SGD included
+    since round 5): every row must reproduce the reference's ser_by_word and end on its weights."""
     from meta_viterbinet_amd.trials import TrialBank, eval_by_word_batched
 
     g, g7 = golden("g12_by_word_with_updates" if tag in ("selfsup", "meta") else "g13_by_word_switches"), golden("g7_by_word")
@@ -437,7 +437,7 @@ def test_reference_by_word_flow_batched_trials(golden, dev, tag):
     rx = torch.tensor(g[f"{tag}_rx"], device=dev).unsqueeze(0).repeat(R, 1, 1)
     bank = TrialBank([[g7[f"w{i}"] for i in range(6)]] * R, 16, 4, dev, **opt)
     draws = [RecordedTableDraws(g, tag, kw["self_supervised_iterations"], subframes, dev) for _ in range(R)]
-    if opt:  # trial after trial through harness.eval_by_word: the draws are asked for in call order
+    if opt and kw.get("online_meta"):  # trial after trial through harness.eval_by_word: the draws are asked for in call order
         draws = [_recorded(g, tag, dev) for _ in range(R)]
     ser = eval_by_word_batched(bank, tx, rx, nsym, subframes, draws, **kw)
     ref = g[f"{tag}_ser_by_word"]

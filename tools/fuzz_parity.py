@@ -20,7 +20,7 @@ rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = torch.device("cuda:0")
 lib, st, ptr = mvn._lib.load(), mvn._lib.current_stream(dev), mvn._lib.ptr
 ENV = ["MVN_SWEEP16", "MVN_VA16", "MVN_VA_INPLACE", "MVN_SWEEP_INPLACE", "MVN_GENERIC_SWEEP", "MVN_UNFUSED", "MVN_FUSEDN", "MVN_COOP",
-       "MVN_FUSED_IP"]
+       "MVN_FUSED_IP", "MVN_DEALT"]
 
 
 def strided(a, pad):
@@ -50,6 +50,8 @@ while time.time() < t_end:
         os.environ["MVN_FUSEDN"] = str(rng.choice(["2", "4"]))
         if rng.rand() < 0.5:
             os.environ["MVN_COOP"] = str(rng.choice(["0", "1"]))
+        if rng.rand() < 0.5:  # the dealt kernel: off / a pinned ring size (raised to the smallest the batch allows)
+            os.environ["MVN_DEALT"] = str(rng.choice(["0", "8", "4", "2"]))
     if rng.rand() < 0.3:
         os.environ["MVN_VA_INPLACE"] = "1"
     if rng.rand() < 0.3:
@@ -74,6 +76,9 @@ while time.time() < t_end:
             cost = rng.normal(0, 2, (B, T, S)).astype(np.float32)
             if rng.rand() < 0.5:
                 cost = np.round(cost)  # exact ties between states
+            if rng.rand() < 0.2:  # odd costs: the sweeps follow torch.min (round 5)
+                for _ in range(int(rng.randint(1, 4))):
+                    cost[rng.randint(B), rng.randint(T), rng.randint(S)] = rng.choice([np.nan, np.inf, -np.inf, 3e38, -3e38])
             rdec, rfm = oracle.acs_sweep(cost)
             ct = torch.tensor(cost, device=dev)
             rc = lib.mvn_acs_sweep_f32(ptr(ct), ptr(dec), T + pad_d, ptr(fm), B, T, S, st)
@@ -89,7 +94,9 @@ while time.time() < t_end:
             wt = [torch.tensor(a, device=dev) for a in w]
             # with logits_out the logits are materialised (S != 16: the two-kernel route); without, the fused kernels run
             lg = torch.empty(B, T, S, device=dev) if rng.rand() < 0.5 else None
-            ws = torch.empty(B * T * S * 4, dtype=torch.uint8, device=dev) if lg is None else None
+            # scratch of the two-kernel route / the dealt 16-state kernel's hand-off lines (given or withheld at random at 16 states)
+            nb16 = int(lib.mvn_vnet_workspace_bytes(B, T, S)) if S == 16 and rng.rand() < 0.7 else 0
+            ws = torch.empty(max(B * T * S * 4, nb16), dtype=torch.uint8, device=dev) if (lg is None or nb16) else None
             rc = lib.mvn_vnet_decode_f32(ptr(yt), T + pad_y, *[ptr(a) for a in wt], ptr(dec), T + pad_d, ptr(lg), ptr(fm),
                                          ptr(ws), 0 if ws is None else ws.numel(), B, T, S, st)
     torch.cuda.synchronize()
