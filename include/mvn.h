@@ -137,16 +137,17 @@ int mvn_vnet_logits_f32(const float *y, const float *W1, const float *b1, const 
                         int64_t N, int32_t S, mvn_stream_t stream);
 
 /* Bytes of scratch mvn_vnet_decode_f32 / mvn_vnet_decode_count_f32 want to run (B,T,S) in one pass.
- *  - Two-kernel route (S = 2, S = 128 / 256 by default, MVN_UNFUSED=1): the logits of the batch; any size that holds
- *    at least one block (T*S*4 bytes) is accepted and processed in slices.
+ *  - Two-kernel route (S = 2; S = 256; every other S != 16 below the batch size from which the fused kernel is the faster
+ *    route -- about 6 blocks per CU at 4 ... 64 states, 14 at 128; MVN_UNFUSED=1): the logits of the batch; any size that
+ *    holds at least one block (T*S*4 bytes) is accepted and processed in slices.
  *  - S = 16, more than 768 blocks: at most 100 KB of hand-off lines for the dealt kernel (vnet16_dealt_kernel: the batch's
  *    32-symbol units shared evenly by 3 workgroups per CU, a block's 16 path metrics handed from wave to wave); 128-byte
  *    aligned, contents irrelevant before and after, not to be shared by calls that may run concurrently.  Without it
  *    (NULL / smaller / unaligned) the one-wave-per-block kernel runs: same bits, 4 % slower at 10 000 x 1000 and up to 2 x at
  *    a thousand blocks.  Word 0 of the workspace is a status word: non-zero after the call only if a hand-off wait was
  *    abandoned (the lower-numbered workgroup it waits for did not publish within seconds; the affected decisions are NaN).
- *  - 0 when the shape is served by a fused kernel that needs none (S = 4 ... 64 by default, S = 128 and 256 with
- *    MVN_FUSED_IP=1; S = 16 up to 768 blocks of up to 1024 symbols: the cooperative kernel). */
+ *  - 0 when the shape is served by a fused kernel that needs none (S = 4 ... 128 from those batch sizes, any batch and
+ *    S = 256 with MVN_FUSED_IP=1; S = 16 up to 768 blocks of up to 1024 symbols: the cooperative kernel). */
 size_t mvn_vnet_workspace_bytes(int64_t B, int32_t T, int32_t S);
 
 /*

@@ -583,14 +583,20 @@ inline char sw(Switch i) {
 bool unfused_forced() { return sw(SW_UNFUSED) == '1'; }
 
 // ViterbiNet at S != 16: vnet_fused_ip_kernel<LB> (MLP inside the in-place sweep, no logits in HBM, no scratch) is the default
-// where it is also the faster route -- 4, 8, 32, 64 states: 1.05-1.11 x the two-kernel route at 10 000 blocks x 1000 -- and
-// opt-in (MVN_FUSED_IP=1) at 128 and 256 states, where a wave's chunk image and the W3 image leave one workgroup per CU and the
-// two-kernel route is 1.2-1.5 x faster (profiles/r04_time_vnet_states.txt).  MVN_FUSED_IP=0 / MVN_UNFUSED=1: never.
-bool fused_ip_selected(int S) {
+// where it is also the faster route (round 5, tools/time_vnet_states.py -> profiles/r05_time_vnet_states.txt):
+//   * 4, 8, 32, 64 states from ~1 500 blocks (three two-block waves per CU; 10 000 x 1000: 1.33-1.45 x the two-kernel route);
+//   * 128 states from ~3 600 blocks (seven per CU; 4 000 x 1000: 1.21 x, 10 000: 1.26 x);
+//   * smaller batches are a few lone waves, each running its two blocks' MLP serially, while mlp_kernel spreads the symbols of
+//     ALL blocks over the chip: the two-kernel route wins (1 000 x 1000: 1.2-1.5 x);
+//   * 256 states: opt-in (MVN_FUSED_IP=1): the W3 and chunk images leave four waves per CU, the two-kernel route is 1.35 x faster.
+// MVN_FUSED_IP=1: whenever it can serve; MVN_FUSED_IP=0 / MVN_UNFUSED=1: never.  (Without a device the rule assumes 256 CUs.)
+bool fused_ip_selected(int S, int64_t B) {
     if (unfused_forced() || S == 16 || S < 4 || S > 256 || (S & (S - 1))) return false;
     const char e = sw(SW_FUSED_IP);
     if (e == '0' || e == '1') return e == '1';
-    return S <= 64;
+    if (S > 128) return false;
+    const int cus = current_device_cus();
+    return (B + 1) / 2 >= (int64_t)(S <= 64 ? 3 : 7) * (cus > 0 ? cus : 256);
 }
 
 // The cooperative kernel (vnet16_coop.inc: a 16-wave workgroup per block, one wave sweeping all T steps after the others' MLP
@@ -1249,7 +1255,7 @@ int mvn_vnet_decode_kernel_name(int64_t B, int32_t T, int32_t S, int32_t want_lo
             snprintf(name, (size_t)name_len, "vnet16_dealt_kernel<%s> rings of %d", want_logits ? "true" : "false", dp.ring);
         else
             snprintf(name, (size_t)name_len, "vnet16_fusedn_kernel<%s, %d>", want_logits ? "true" : "false", fusedn_tiles());
-    } else if (!want_logits && fused_ip_selected(S)) {  // one kernel: the MLP fused into the in-place sweep
+    } else if (!want_logits && fused_ip_selected(S, B)) {  // one kernel: the MLP fused into the in-place sweep
         snprintf(name, (size_t)name_len, "vnet_fused_ip_kernel<%d>", log2_states(S) - 2);
     } else {  // two launches: the MLP, then the sweep over its logits (scratch or logits_out: 16-byte aligned, row stride T)
         char sw[64];
@@ -1285,7 +1291,7 @@ int mvn_vnet_logits_f32(const float *y, const float *W1, const float *b1, const 
 size_t mvn_vnet_workspace_bytes(int64_t B, int32_t T, int32_t S) {
     if (B <= 0 || T <= 0 || S <= 0) return 0;
     if (S == 16 && !unfused_forced()) return dealt_workspace_bytes_for(B, T);  // hand-off lines of the dealt kernel (<= 100 KB), or 0
-    if (fused_ip_selected(S)) return 0;  // the fused kernels keep the logits on chip
+    if (fused_ip_selected(S, B)) return 0;  // the fused kernels keep the logits on chip
     return (size_t)B * (size_t)T * (size_t)S * sizeof(float);
 }
 
@@ -1301,7 +1307,7 @@ int mvn_vnet_decode_f32(const float *y, int64_t y_ld, const float *W1, const flo
     if (S == 16 && !unfused_forced())  // fused single-kernel path: no scratch, 8 B/symbol of HBM traffic
         return launch_vnet16_fused(y, y_ld, W1, b1, W2, b2, W3, b3, dec, dec_ld, logits_out, final_metric, B, T, nullptr, 0,
                                    0, nullptr, nullptr, st, workspace, workspace_bytes);
-    if (!logits_out && fused_ip_selected(S))  // other state counts: the MLP fused into the in-place sweep
+    if (!logits_out && fused_ip_selected(S, B))  // other state counts: the MLP fused into the in-place sweep
         return launch_vnet_fused_ip(y, y_ld, W1, b1, W2, b2, W3, b3, dec, dec_ld, final_metric, B, T, S, st);
     const size_t per_block = (size_t)T * (size_t)S * sizeof(float);
     int64_t slice = B;

@@ -64,9 +64,11 @@ def test_argument_validation_needs_no_device(lib):
     assert lib.mvn_acs_sweep_f32(None, None, 8, None, 4, 8, 16, None) == -4
     assert lib.mvn_count_errors(None, 4, None, 4, None, 2, 4, None, None) == -4
     assert lib.mvn_vnet_workspace_bytes(10, 100, 2) == 10 * 100 * 2 * 4  # two states: the two-kernel route (logits in scratch)
-    for S in (4, 8, 16, 32, 64):
-        assert lib.mvn_vnet_workspace_bytes(10, 100, S) == 0  # fused kernels: logits never leave the chip
-    assert lib.mvn_vnet_workspace_bytes(10, 100, 256) == 10 * 100 * 256 * 4  # (fused on request only: MVN_FUSED_IP=1)
+    assert lib.mvn_vnet_workspace_bytes(10, 100, 16) == 0  # (the cooperative kernel: no hand-off lines either)
+    for S in (4, 8, 32, 64, 128):  # fused kernels: logits never leave the chip -- from the batch size where that is the faster route
+        assert lib.mvn_vnet_workspace_bytes(10000, 1000, S) == 0
+        assert lib.mvn_vnet_workspace_bytes(10, 100, S) == 10 * 100 * S * 4  # a few blocks: mlp_kernel + sweep over logits in scratch
+    assert lib.mvn_vnet_workspace_bytes(10000, 100, 256) == 10000 * 100 * 256 * 4  # (fused on request only: MVN_FUSED_IP=1)
     # the by-word step: 16 states, whole bytes, nsym <= 8, a row stride for every output that is given
     step = lambda T, nsym, S, R=1, rx_ld=None: lib.mvn_vnet_byword_step_f32(  # noqa: E731
         None, T if rx_ld is None else rx_ld, None, T, *([None] * 6), None, None, T, None, T, None, T, None, T, None, T, None, R, T,

@@ -251,12 +251,14 @@ def test_vnet16_fused_and_unfused_paths(oracle, dev, monkeypatch, B, T):
 
 
 @pytest.mark.parametrize("S", [4, 8, 32, 64, 128, 256])
-@pytest.mark.parametrize("B,T", [(1, 1), (3, 7), (5, 17), (70, 136), (9, 1000), (260, 33)])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 7), (5, 17), (70, 136), (9, 1000), (260, 33), (1101, 33), (10301, 9)])
 def test_vnet_fused_ip_and_two_kernel_routes(oracle, dev, monkeypatch, S, B, T):
-    """Every S other than 16 (and 2): vnet_fused_ip_kernel<LB> -- the MLP fused into the in-place sweep, logits never in HBM --
-    by default, MVN_UNFUSED=1 the two-kernel route (mlp_kernel -> logits -> sweep_inplace_kernel).  Both give the oracle's
-    decisions and final path metrics bit for bit: blocks that do not fill a wave, T that is not a multiple of the chunk, a tile
-    that leaves the fast sigmoid's range, decision rows that are not 16-byte aligned (scalar stores) and a padded y stride."""
+    """Every S other than 16 (and 2): vnet_fused_ip_kernel<LB> -- the MLP fused into the in-place sweep, logits never in HBM
+    (the default from a few thousand blocks, pinned here) -- and MVN_UNFUSED=1 the two-kernel route (mlp_kernel -> logits ->
+    sweep_inplace_kernel).  Both give the oracle's decisions and final path metrics bit for bit: blocks that do not fill a wave,
+    T that is not a multiple of the chunk (or of the half chunk the image holds at 128 states), a tile that leaves the fast
+    sigmoid's range, decision rows that are not 16-byte aligned (scalar stores), a padded y stride, a batch spread over every CU
+    with two and a half active waves per workgroup (1 101 blocks) and one of several rounds of full workgroups (10 301)."""
     rng = np.random.RandomState(S + 3 * B + T)
     w = _rand_weights(S, rng, scale=2.0)
     y = rng.normal(0, 2, (B, T)).astype(np.float32)
@@ -341,7 +343,10 @@ def test_sweep16_quad_variant(oracle, dev, monkeypatch):
     monkeypatch.setenv("MVN_DEALT", "0")  # (also what runs when the caller passes no hand-off workspace)
     assert (lib.mvn_vnet_decode_kernel_name(10000, 1000, 16, 0, buf, 64), buf.value) == (0, b"vnet16_fusedn_kernel<false, 2>")
     monkeypatch.delenv("MVN_DEALT")
-    assert (lib.mvn_vnet_decode_kernel_name(10, 100, 64, 0, buf, 64), buf.value) == (0, b"vnet_fused_ip_kernel<4>")  # MLP inside the sweep
+    assert (lib.mvn_vnet_decode_kernel_name(10000, 1000, 64, 0, buf, 64), buf.value) == (0, b"vnet_fused_ip_kernel<4>")  # MLP inside the sweep
+    assert (lib.mvn_vnet_decode_kernel_name(4000, 1000, 128, 0, buf, 64), buf.value) == (0, b"vnet_fused_ip_kernel<5>")
+    assert (lib.mvn_vnet_decode_kernel_name(10, 100, 64, 0, buf, 64), buf.value) == (0, b"mlp_kernel<4> + sweep_inplace_kernel<4, 1, 4>")  # a few blocks
+    assert (lib.mvn_vnet_decode_kernel_name(1000, 1000, 128, 0, buf, 64), buf.value)[1].startswith(b"mlp_kernel<8> + ")
     assert (lib.mvn_vnet_decode_kernel_name(10, 100, 64, 1, buf, 64), buf.value) == (0, b"mlp_kernel<4> + sweep_inplace_kernel<4, 1, 4>")  # logits wanted
     assert (lib.mvn_vnet_decode_kernel_name(10, 100, 256, 0, buf, 64), buf.value) == (0, b"mlp_kernel<16> + sweep_inplace_kernel<6, 1, 4>")  # fused on request only
     rng = np.random.RandomState(77)
@@ -1551,8 +1556,9 @@ def test_sweeps_follow_torch_min_on_odd_costs(oracle, dev, monkeypatch, S, varia
 VNET_NAN_ROUTES = [(16, {"MVN_COOP": "1"}), (16, {"MVN_COOP": "0"}), (16, {"MVN_COOP": "0", "MVN_FUSEDN": "4"}),
                    (16, {"MVN_UNFUSED": "1", "MVN_SWEEP16": "rows"}), (16, {"MVN_UNFUSED": "1", "MVN_SWEEP16": "lds"}),
                    (16, {"MVN_UNFUSED": "1", "MVN_SWEEP16": "quad"}), (16, {"MVN_UNFUSED": "1", "MVN_SWEEP_INPLACE": "1"}),
-                   (4, {}), (8, {}), (32, {}), (64, {}), (128, {"MVN_FUSED_IP": "1"}), (256, {"MVN_FUSED_IP": "1"}),  # vnet_fused_ip_kernel<LB>
-                   (128, {}), (256, {}),
+                   (4, {"MVN_FUSED_IP": "1"}), (8, {"MVN_FUSED_IP": "1"}), (32, {"MVN_FUSED_IP": "1"}), (64, {"MVN_FUSED_IP": "1"}),
+                   (128, {"MVN_FUSED_IP": "1"}), (256, {"MVN_FUSED_IP": "1"}),  # vnet_fused_ip_kernel<LB>
+                   (4, {}), (32, {}), (128, {}), (256, {}),  # (a few blocks: the two-kernel route by default)
                    (4, {"MVN_UNFUSED": "1"}), (8, {"MVN_UNFUSED": "1"}), (64, {"MVN_UNFUSED": "1"}), (256, {"MVN_UNFUSED": "1"}),
                    (64, {"MVN_UNFUSED": "1", "MVN_GENERIC_SWEEP": "1"}), (2, {})]
 
