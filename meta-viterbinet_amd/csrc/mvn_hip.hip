@@ -973,6 +973,8 @@ template <class Launch>  // launch(SC tag): picks the instantiation for S
 int dispatch_states(int S, bool many, Launch launch) {
     if (S == 16) return launch(std::integral_constant<int, 16>{});
     if (S == 32 && !many) return launch(std::integral_constant<int, 32>{});  // (R trials at S = 32 take the run-time form)
+    if (S == 64) return launch(std::integral_constant<int, 64>{});   // } online training only (launch_online_train)
+    if (S == 128) return launch(std::integral_constant<int, 128>{}); // }
     return launch(std::integral_constant<int, 0>{});
 }
 
@@ -980,7 +982,7 @@ int dispatch_states(int S, bool many, Launch launch) {
 // for mvn_vnet_train_kernel_name, so that the form a test or a profile is told is the form that runs.  `many`: the
 // trial-batched entry points (R trials); has_workspace / workspace_bytes as the caller passed them.
 int plan_online_groups(bool many, int R, int T, int M, int S, bool has_workspace, size_t workspace_bytes) {
-    const int groups = M > 0 ? 0 : online_groups(T);  // minibatch iterations are one chunk: nothing to spread
+    const int groups = M > 0 || S > 32 ? 0 : online_groups(T);  // minibatch iterations are one chunk: nothing to spread; 64 / 128 states: one workgroup
     const int cus = current_device_cus();
     if (groups < 2 || !has_workspace || sw(SW_TRAIN_GROUPS) == '0' || groups > cus) return 0;
     if (workspace_bytes < (many ? (size_t)R * trial_workspace_floats(S, groups) * sizeof(float) : train_groups_workspace_bytes(S, groups)))
@@ -1026,10 +1028,11 @@ int launch_online_train(const mvn_train_trial_t &one, const mvn_train_trial_t *m
     if (!groups) {  // one workgroup per trial
         return dispatch_states(S, many != nullptr, [&](auto sc) -> int {
             constexpr int SC = decltype(sc)::value;
-            if (many && online_pair_form(true, R, M, S)) {
+            if (many && online_pair_form(true, R, M, S)) {  // (16 states only)
+                constexpr int SC2 = SC >= 32 ? 0 : SC;
                 const size_t lds2 = online_train2_lds_bytes(S);
-                if (int e = ensure_dynamic_lds((const void *)online_train_kernel<SC == 32 ? 0 : SC, true, kTrainThreads2>, lds2)) return e;
-                hipLaunchKernelGGL((online_train_kernel<SC == 32 ? 0 : SC, true, kTrainThreads2>), dim3(1, (unsigned)R), dim3(kTrainThreads2),
+                if (int e = ensure_dynamic_lds((const void *)online_train_kernel<SC2, true, kTrainThreads2>, lds2)) return e;
+                hipLaunchKernelGGL((online_train_kernel<SC2, true, kTrainThreads2>), dim3(1, (unsigned)R), dim3(kTrainThreads2),
                                    lds2, st, one, many, T, M, lr, beta1, beta2, eps, S, (int)online_train2_lds_floats(S));
             } else if (many) {
                 if (int e = ensure_dynamic_lds((const void *)online_train_kernel<SC == 32 ? 0 : SC, true>, lds)) return e;
@@ -1056,7 +1059,7 @@ int launch_online_train(const mvn_train_trial_t &one, const mvn_train_trial_t *m
                                 xcd ? groups : 0, nr, next_xcd_slot(xcd, many != nullptr)};
         const dim3 grid = xcd ? dim3(group_grid_blocks(groups, nr)) : dim3((unsigned)groups, (unsigned)nr);
         const int rc = dispatch_states(S, many != nullptr, [&](auto sc) -> int {
-            constexpr int SC = decltype(sc)::value;
+            constexpr int SC = decltype(sc)::value > 32 ? 0 : decltype(sc)::value;  // (never above 32 states: plan_online_groups)
             if (many) {
                 if (int e2 = ensure_dynamic_lds((const void *)online_train_groups_kernel<SC == 32 ? 0 : SC, true>, lds)) return e2;
                 hipLaunchKernelGGL((online_train_groups_kernel<SC == 32 ? 0 : SC, true>), grid,
@@ -1084,7 +1087,7 @@ int launch_maml_train(const mvn_train_trial_t &one, const mvn_train_trial_t *man
     if (groups && (reinterpret_cast<uintptr_t>(workspace) & 15)) return MVN_E_WORKSPACE;
     if (!groups) {
         return dispatch_states(S, many != nullptr, [&](auto sc) -> int {
-            constexpr int SC = decltype(sc)::value;
+            constexpr int SC = decltype(sc)::value > 32 ? 0 : decltype(sc)::value;  // (the meta-learning kernels: up to 32 states)
             if (many) {
                 if (int e = ensure_dynamic_lds((const void *)maml_train_kernel<SC == 32 ? 0 : SC, true>, lds)) return e;
                 hipLaunchKernelGGL((maml_train_kernel<SC == 32 ? 0 : SC, true>), dim3(1, (unsigned)R), dim3(kTrainThreads), lds, st, one,
@@ -1109,7 +1112,7 @@ int launch_maml_train(const mvn_train_trial_t &one, const mvn_train_trial_t *man
                                 xcd ? groups : 0, nr, next_xcd_slot(xcd, many != nullptr)};
         const dim3 grid = xcd ? dim3(group_grid_blocks(groups, nr)) : dim3((unsigned)groups, (unsigned)nr);
         const int rc = dispatch_states(S, many != nullptr, [&](auto sc) -> int {
-            constexpr int SC = decltype(sc)::value;
+            constexpr int SC = decltype(sc)::value > 32 ? 0 : decltype(sc)::value;  // (the meta-learning kernels: up to 32 states)
             if (many) {
                 if (int e2 = ensure_dynamic_lds((const void *)maml_train_groups_kernel<SC == 32 ? 0 : SC, true>, lds)) return e2;
                 hipLaunchKernelGGL((maml_train_groups_kernel<SC == 32 ? 0 : SC, true>), grid,
@@ -1370,7 +1373,7 @@ int mvn_vnet_online_train_ws_f32(const float *y, const int32_t *labels, int32_t 
                                  float *loss_out, int32_t S, void *workspace, size_t workspace_bytes, int32_t *status,
                                  mvn_stream_t stream) {
     if (T < 1 || n_iter < 0 || step0 < 0 || (batch_idx && M < 1)) return MVN_E_DIMS;
-    if (!valid_states(S) || S > 32) return MVN_E_STATES;  // parameters + Adam moments must fit the 160-KB LDS
+    if (!valid_states(S) || S > 128) return MVN_E_STATES;  // parameters + gradient + a chunk must fit the 160-KB LDS
     if (n_iter == 0) return MVN_OK;
     if (!y || !labels || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !adam_m || !adam_v) return MVN_E_NULL;
     mvn_train_trial_t d = {};
@@ -1397,7 +1400,7 @@ int mvn_vnet_online_train_trials_f32(const mvn_train_trial_t *trials, int32_t R,
                                      float beta2, float eps, int32_t S, void *workspace, size_t workspace_bytes,
                                      mvn_stream_t stream) {
     if (T < 1 || R < 0 || M < 0) return MVN_E_DIMS;
-    if (!valid_states(S) || S > 32) return MVN_E_STATES;
+    if (!valid_states(S) || S > 128) return MVN_E_STATES;
     if (R == 0) return MVN_OK;
     if (!trials) return MVN_E_NULL;
     return launch_online_train(mvn_train_trial_t{}, trials, R, T, M, lr, beta1, beta2, eps, S, workspace, workspace_bytes,
@@ -1459,13 +1462,13 @@ int mvn_vnet_maml_train_trials_f32(const mvn_train_trial_t *trials, int32_t R, i
 int mvn_vnet_train_kernel_name(int32_t kind, int32_t R, int32_t T, int32_t M_or_W, int32_t S, size_t workspace_bytes, char *name,
                                int32_t name_len) {
     if (kind < 0 || kind > 2 || R < 0 || T < 1 || M_or_W < 0 || (kind > 0 && M_or_W < 1)) return MVN_E_DIMS;
-    if (!valid_states(S) || S > 32) return MVN_E_STATES;
+    if (!valid_states(S) || S > (kind == 0 ? 128 : 32)) return MVN_E_STATES;
     if (!name || name_len < 1) return MVN_E_NULL;
     const bool many = R > 0;
     const int n_trials = many ? R : 1;
     const int groups = kind == 0 ? plan_online_groups(many, n_trials, T, M_or_W, S, workspace_bytes > 0, workspace_bytes)
                                  : plan_maml_groups(many, n_trials, T, M_or_W, kind == 2, S, workspace_bytes > 0, workspace_bytes);
-    const int sc = S == 16 ? 16 : (S == 32 && !many) ? 32 : 0;  // dispatch_states
+    const int sc = S == 16 ? 16 : (S == 32 && !many) ? 32 : S > 32 ? S : 0;  // dispatch_states
     const char *base = kind == 0 ? "online_train" : "maml_train";
     if (!groups && kind == 0 && online_pair_form(many, n_trials, M_or_W, S)) {
         snprintf(name, (size_t)name_len, "%s_kernel<%d, true, %d> 1x%d", base, sc, kTrainThreads2, n_trials);

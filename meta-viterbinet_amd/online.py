@@ -184,7 +184,9 @@ class OnlineTrainer:
         labels: int32 [T], the trellis states of tx when the caller already has them (kernel route only); None: calculate_states(tx)."""
         p = self.params
         dev = p[0].device
-        if p[5].numel() > 32 or not self.use_kernel:  # the one-launch kernel keeps parameters + both Adam moments in LDS: n_states <= 32
+        # the one-launch kernel keeps parameters, gradient and a chunk's activations in LDS: n_states <= 128 (up to 32 with both
+        # moments beside them; 64 / 128: the moments stay in global memory)
+        if p[5].numel() > 128 or not self.use_kernel:
             return self._online_training_autograd(tx, rx, iterations, batch_idx, full_word, return_loss)
         _lib.require_gpu_tensor(rx, "rx")
         _lib.require_gpu_tensor(p[0], "detector parameters")
@@ -221,8 +223,8 @@ class OnlineTrainer:
 
     def _online_training_autograd(self, tx, rx, iterations, batch_idx, full_word, return_loss):
         """The same loop on stock PyTorch autograd (run_train_loop, trainer.py:492-505: forward 'train', CrossEntropy over the
-        selected samples, backward, Adam on the shared exp_avg / exp_avg_sq / step): the route for memory_length >= 6, whose
-        parameter set does not fit the training kernel's LDS image.  Same draws as the kernel path (select_batches)."""
+        selected samples, backward, Adam on the shared exp_avg / exp_avg_sq / step): the route for memory_length 8 (256 states), whose
+        parameter set does not fit the training kernel's LDS image, and for use_kernel=False.  Same draws as the kernel path (select_batches)."""
         import torch.nn.functional as F
 
         p = self.params

@@ -660,6 +660,22 @@ def g16_by_word_other_state_counts():
     save("g16_by_word_other_state_counts", **out)
 
 
+def g17_by_word_64_128_states():
+    """eval_by_word with self-supervised updates at channel memories 6 and 7 (64 and 128 states; round 5: online_train_kernel<64 | 128>,
+    parameters + gradient in LDS, the optimizer's moments in global memory): ViterbiNet briefly trained by the reference's own
+    trainer, then 50 blocks of the self-supervised flow, recorded like G16.  (The meta-learning kernel stops at 32 states.)"""
+    out = {}
+    selfsup = dict(self_supervised=True, self_supervised_iterations=8, online_meta=False)
+    for L in (6, 7):
+        import contextlib
+        import io
+
+        with contextlib.redirect_stdout(io.StringIO()):
+            w = export_weights(train_vnet(L, 10).detector)
+        _by_word_flow(out, f"L{L}_selfsup", VNETTrainer, dict(selfsup, memory_length=L, fading_in_channel=False), None, 2, weights=w)
+    save("g17_by_word_64_128_states", **out)
+
+
 # ----------------------------------------------------------------------------- G14
 def g14_aggregated_evaluate():
     """Trainer.evaluate() in 'aggregated' mode (trainer.py:368-381 -> evaluate_at_point :254-265 -> gamma_eval :243-252 ->
@@ -761,14 +777,14 @@ if __name__ == "__main__":
         g15_by_word_reference_defaults()
         g16_by_word_other_state_counts()
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] in ("g12", "g13", "g15", "g16"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("g12", "g13", "g15", "g16", "g17"):
         import contextlib
         import io
 
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):  # (the reference prints every block)
             {"g12": g12_by_word_with_updates, "g13": g13_by_word_switches, "g15": g15_by_word_reference_defaults,
-             "g16": g16_by_word_other_state_counts}[sys.argv[1]]()
+             "g16": g16_by_word_other_state_counts, "g17": g17_by_word_64_128_states}[sys.argv[1]]()
         print("\n".join(l for l in buf.getvalue().splitlines() if l.startswith(("g12", "wrote"))))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g10":

@@ -845,6 +845,64 @@ def test_online_training_vs_torch(dev, n_iter, full_word, M):
         assert np.all(np.abs(_np(p) - ref_w[i]) <= 2e-5 + 1e-3 * np.abs(ref_w[i])), i
 
 
+@pytest.mark.parametrize("S,L", [(64, 6), (128, 7)])
+@pytest.mark.parametrize("n_iter,full_word,M,optimizer", [(1, False, 32, "Adam"), (8, False, 32, "Adam"), (3, True, 32, "Adam"), (5, False, 17, "Adam"),
+                                                         (4, False, 70, "Adam"), (6, False, 32, "RMSprop"), (3, True, 32, "SGD")])
+def test_online_training_at_64_and_128_states_vs_torch(dev, S, L, n_iter, full_word, M, optimizer):
+    """Channel memories 6 and 7 (64 / 128 trellis states; trainer.py:163-185 takes any memory_length): online_train_kernel<64|128>
+    -- parameters, gradient and a chunk's activations in LDS, the optimizer's moments in global memory, a wave per sample in the
+    softmax -- against torch autograd + torch.optim on the same word and draws, the optimizer state carried over two calls; also
+    through the trial-batched entry point's descriptor (the kernel name tells which instantiation runs).  Tolerance as at 16 states."""
+    T = 136
+    rng = np.random.RandomState(S + n_iter + M)
+    w = _rand_weights(S, rng)
+    tx = rng.randint(0, 2, (1, T)).astype(np.float32)
+    y = rng.normal(0, 1.5, (1, T)).astype(np.float32)
+    labels = mvn.calculate_states(L, torch.tensor(tx)).numpy()
+    assert labels.max() >= S // 2  # the labels use the upper half of the states
+    idx = np.stack([rng.choice(np.arange(1, T), M, replace=False) for _ in range(n_iter)]).astype(np.int32)
+    lr = 0.05 if optimizer == "SGD" else 1e-3
+    ref_w, ref_loss = _torch_online_ref(w, y[0], labels, idx, lr, n_iter, full_word, optimizer)
+    det = _vnet_with(w, S, T, dev)
+    tr = mvn.OnlineTrainer(det, L, lr=lr, optimizer_type=optimizer)
+    name = ctypes.create_string_buffer(96)
+    assert mvn._lib.load().mvn_vnet_train_kernel_name(0, 0, T, 0 if full_word else M, S, 1 << 22, name, 96) == 0
+    assert name.value.decode() == f"online_train_kernel<{S}, false> 1x1"
+    n1 = n_iter // 2
+    l1 = tr.online_training(torch.tensor(tx, device=dev), torch.tensor(y, device=dev), iterations=n1,
+                            batch_idx=torch.tensor(idx[:n1], device=dev), full_word=full_word, return_loss=True) if n1 else None
+    l2 = tr.online_training(torch.tensor(tx, device=dev), torch.tensor(y, device=dev), iterations=n_iter - n1,
+                            batch_idx=torch.tensor(idx[n1:], device=dev), full_word=full_word, return_loss=True)
+    loss = np.concatenate([_np(l1), _np(l2)]) if n1 else _np(l2)
+    assert np.allclose(loss, ref_loss, rtol=2e-4, atol=1e-6)
+    for i, p in enumerate(det.net.parameters()):
+        assert np.all(np.abs(_np(p) - ref_w[i]) <= 2e-5 + 1e-3 * np.abs(ref_w[i])), i
+    if M == 32 and not full_word:  # the same iterations as three trials of one launch of the trial-batched entry point
+        from meta_viterbinet_amd import trials as tr_mod
+
+        R, lib = 3, mvn._lib.load()
+        bank = tr_mod.TrialBank([w] * R, S, L, dev, lr=lr, optimizer_type=optimizer)
+        yt = torch.tensor(y, device=dev).repeat(R, 1).contiguous()
+        lab = torch.tensor(labels, device=dev).to(torch.int32).reshape(1, T).repeat(R, 1).contiguous()
+        bidx = torch.tensor(idx, device=dev).unsqueeze(0).repeat(R, 1, 1).contiguous()
+        th = bank.pointers(bank.theta)
+        d = np.zeros(R, dtype=tr_mod.TRIAL_DTYPE)
+        for r in range(R):
+            d[r]["y"], d[r]["labels"], d[r]["idx"] = yt[r].data_ptr(), lab[r].data_ptr(), bidx[r].data_ptr()
+            d[r]["w_in"], d[r]["w_out"] = th[r], th[r]
+            d[r]["adam_m"], d[r]["adam_v"] = bank.exp_avg[r].data_ptr(), bank.exp_avg_sq[r].data_ptr()
+            d[r]["b1pow"], d[r]["b2pow"] = 1.0, 1.0
+            d[r]["n"] = n_iter
+        dd = torch.from_numpy(d.view(np.uint8)).to(dev)
+        assert lib.mvn_vnet_train_kernel_name(0, R, T, M, S, 0, name, 96) == 0 and name.value.decode() == f"online_train_kernel<{S}, true> 1x{R}"
+        b1, b2, eps = {"Adam": (0.9, 0.999, 1e-8), "RMSprop": (-1.0, 0.99, 1e-8), "SGD": (-2.0, 0.0, 0.0)}[optimizer]
+        assert lib.mvn_vnet_online_train_trials_f32(mvn._lib.ptr(dd), R, T, M, lr, b1, b2, eps, S, None, 0, mvn._lib.current_stream(dev)) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(bank.theta[0], bank.theta[1]) and torch.equal(bank.theta[0], bank.theta[2])
+        for i, t in enumerate(bank.weights(0)):
+            assert np.all(np.abs(_np(t) - ref_w[i]) <= 2e-5 + 1e-3 * np.abs(ref_w[i])), i
+
+
 @pytest.mark.parametrize("optimizer,lr", [("RMSprop", 1e-3), ("SGD", 0.05)])
 @pytest.mark.parametrize("n_iter,full_word,form", [(12, False, "one"), (5, True, "chunked"), (5, True, "one"), (9, False, "trials")])
 def test_online_training_other_optimizers_vs_torch(dev, monkeypatch, optimizer, lr, n_iter, full_word, form):

@@ -83,7 +83,7 @@ class RecordedDraws:
 
 # the harness arguments of every recorded flow beyond its iteration counts (tests/golden/make_golden.py: g12 / g13)
 FLOWS = {"selfsup": {}, "meta": dict(online_meta=True), "c2_selfsup": {}, "c4_meta": dict(online_meta=True),
-         "L3_selfsup": {}, "L3_meta": dict(online_meta=True), "L5_selfsup": {}, "L5_meta": dict(online_meta=True), "fomaml": dict(online_meta=True, MAML=False),
+         "L3_selfsup": {}, "L3_meta": dict(online_meta=True), "L5_selfsup": {}, "L5_meta": dict(online_meta=True), "L6_selfsup": {}, "L7_selfsup": {}, "fomaml": dict(online_meta=True, MAML=False),
          "window": dict(online_meta=True, window=True), "random": dict(online_meta=True, weights_init="random"),
          "metatrain": dict(online_meta=True, weights_init="meta_training"), "support2": dict(online_meta=True, window_size=2),
          "rmsprop": dict(optimizer_type="RMSprop"), "sgd": dict(optimizer_type="SGD", lr=0.05)}
@@ -193,18 +193,21 @@ def test_reference_by_word_switches(golden, dev, tag, hip):
 
 
 G16 = ["L3_selfsup", "L3_meta", "L5_selfsup", "L5_meta"]
+G17 = ["L6_selfsup", "L7_selfsup"]
 
 
-@pytest.mark.parametrize("tag", G16)
+@pytest.mark.parametrize("tag", G16 + G17)
 @pytest.mark.parametrize("route", ["hip_kernels", "torch_autograd", "batched_trials"])
 def test_reference_by_word_flow_other_state_counts(golden, dev, tag, route):
     """Golden G16: the self-supervised and the meta-learning flow at 8 and 32 states (channel memory 3 and 5), recorded runs of the
     unmodified reference from weights its own trainer produced: the run-time-n_states instantiations of the training kernels
     (online_train / maml_train _kernel<0, ...>, their chunked forms) and the block step as separate launches (the one-launch step
-    serves 16 states).  ser_by_word identical on all 50 blocks, final weights within 5e-5 of the reference's, on every route."""
+    serves 16 states).  Golden G17 (round 5): the self-supervised flow at 64 and 128 states (memory 6 and 7) on
+    online_train_kernel<64 | 128>.  ser_by_word identical on all 50 blocks, final weights within 5e-5 of the reference's, on
+    every route."""
     from meta_viterbinet_amd.trials import TrialBank, eval_by_word_batched
 
-    g, g7 = golden("g16_by_word_other_state_counts"), golden("g7_by_word")
+    g, g7 = golden("g17_by_word_64_128_states" if tag in G17 else "g16_by_word_other_state_counts"), golden("g7_by_word")
     ref, w0 = g[f"{tag}_ser_by_word"], _start_weights(g, g7, tag)
     S = w0[5].shape[0]
     if route == "batched_trials":
@@ -225,7 +228,7 @@ def test_reference_by_word_flow_other_state_counts(golden, dev, tag, route):
     assert np.array_equal(ser, ref), (np.flatnonzero(ser != ref), ser[ser != ref], ref[ser != ref])
     moved = max(float(np.abs(g[f"{tag}_w1_{i}"] - w0[i]).max()) for i in range(6))
     worst = max(float(np.abs(w[i] - g[f"{tag}_w1_{i}"]).max()) for i in range(6))
-    print(f"g16 {tag} ({S} states) {route}: ser identical on 50 blocks; weights moved {moved:.4f}, end {worst:.2e} from the reference's")
+    print(f"g16/17 {tag} ({S} states) {route}: ser identical on 50 blocks; weights moved {moved:.4f}, end {worst:.2e} from the reference's")
     assert moved > 0.005 and worst <= 5e-5
 
 
