@@ -202,7 +202,8 @@ int mvn_count_errors(const float *dec, int64_t dec_ld, const float *tx, int64_t 
  *   samples every iteration (metavnet_trainer.py:41-50);
  *   W1..b3: parameters, updated in place; adam_m/adam_v: [P] exp_avg / exp_avg_sq in parameter order
  *   (P = 250 + 50*100 + 51*S), updated in place; step0 = Adam steps already taken;
- *   loss_out [n_iter] or NULL.  S <= 32.  fp32; agrees with torch autograd + Adam to rounding, not bitwise.
+ *   loss_out [n_iter] or NULL.  S <= 128 (64 / 128 states: one workgroup per trial, the optimizer's moments stay in global
+ *   memory).  fp32; agrees with torch autograd + Adam to rounding, not bitwise.
  * The trainer's other optimizers (deep_learning_setup, trainer.py:163-175) ride on the same arguments: beta1 = MVN_BETA1_RMSPROP
  * runs torch.optim.RMSprop's update (alpha = beta2, eps; square average in adam_v, adam_m untouched; torch's defaults: no
  * momentum, not centered), beta1 = MVN_BETA1_SGD torch.optim.SGD's (p -= lr g; adam_m / adam_v untouched).  The same holds for

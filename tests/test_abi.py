@@ -83,7 +83,8 @@ def test_argument_validation_needs_no_device(lib):
     assert va_step(136, 2, 16, R=0) == 0 and va_step(136, 2, 16) == -4
     # trial-batched training: shapes before pointers; no trials = nothing to do; workspace sizes
     assert lib.mvn_vnet_online_train_trials_f32(None, 4, 0, 0, 1e-3, 0.9, 0.999, 1e-8, 16, None, 0, None) == -1
-    assert lib.mvn_vnet_online_train_trials_f32(None, 4, 136, 0, 1e-3, 0.9, 0.999, 1e-8, 64, None, 0, None) == -2
+    assert lib.mvn_vnet_online_train_trials_f32(None, 4, 136, 0, 1e-3, 0.9, 0.999, 1e-8, 256, None, 0, None) == -2  # online training: S <= 128
+    assert lib.mvn_vnet_maml_train_trials_f32(None, 4, 136, 1, 0.1, 1, 1e-3, 0.9, 0.999, 1e-8, 64, None, 0, None) == -2  # meta-learning: S <= 32
     assert lib.mvn_vnet_online_train_trials_f32(None, 0, 136, 0, 1e-3, 0.9, 0.999, 1e-8, 16, None, 0, None) == 0
     assert lib.mvn_vnet_online_train_trials_f32(None, 4, 136, 0, 1e-3, 0.9, 0.999, 1e-8, 16, None, 0, None) == -4
     assert lib.mvn_vnet_maml_train_trials_f32(None, 4, 136, 0, 0.1, 1, 1e-3, 0.9, 0.999, 1e-8, 16, None, 0, None) == -1
@@ -107,7 +108,8 @@ def test_train_kernel_name_validates(lib):
     name = ctypes.create_string_buffer(96)
     assert lib.mvn_vnet_train_kernel_name(3, 1, 136, 0, 16, 0, name, 96) == -1
     assert lib.mvn_vnet_train_kernel_name(1, 1, 136, 0, 16, 0, name, 96) == -1  # a meta-learning step has W >= 1 support words
-    assert lib.mvn_vnet_train_kernel_name(0, 1, 136, 0, 64, 0, name, 96) == -2
+    assert lib.mvn_vnet_train_kernel_name(0, 1, 136, 0, 256, 0, name, 96) == -2 and lib.mvn_vnet_train_kernel_name(1, 1, 136, 1, 64, 0, name, 96) == -2
+    assert lib.mvn_vnet_train_kernel_name(0, 1, 136, 0, 64, 0, name, 96) == 0 and name.value == b"online_train_kernel<64, true> 1x1"
     assert lib.mvn_vnet_train_kernel_name(0, 1, 136, 0, 16, 0, None, 96) == -4
     # without a workspace every form is one workgroup per trial; minibatch iterations always are
     assert lib.mvn_vnet_train_kernel_name(0, 0, 136, 0, 16, 0, name, 96) == 0 and name.value == b"online_train_kernel<16, false> 1x1"
