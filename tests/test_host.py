@@ -142,15 +142,15 @@ def test_meta_train_loop_golden(golden, tag, maml):
     assert tr.step == 4
 
 
-def test_online_training_falls_back_to_autograd_above_32_states():
-    """memory_length 6 (64 states): the parameter set does not fit the training kernel's LDS image, so
+def test_online_training_falls_back_to_autograd_above_128_states():
+    """memory_length 8 (256 states): the parameter set does not fit the training kernel's LDS image, so
     OnlineTrainer.online_training runs run_train_loop (trainer.py:492-505) on stock autograd -- same draws, same shared
     Adam state -- instead of raising.  Checked against torch.optim.Adam on a copy (CPU tensors: no GPU needed)."""
     import copy
 
     import torch.nn.functional as F
 
-    L, S, T, iters = 6, 64, 96, 7
+    L, S, T, iters = 8, 256, 96, 7
     torch.manual_seed(3)
     det = mvn.VNETDetector(S, {"train": T, "val": T}).to("cpu")
     det.net.to("cpu")
