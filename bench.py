@@ -214,6 +214,30 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
                 "parallelism": f"block-sharded x{world}, one all-reduce of int64[4] counters"})
     del tx3, y3, dec3
 
+    # ---- ViterbiNet at the other trellis sizes (vnet_detector.py:35-61 takes any n_states): 10 000 blocks x 1000 symbols per GPU,
+    # weights at random initialisation.  FLOP per symbol as for 16 states: 2 (100 + 100 x 50 + 50 S) + biases / activations + ACS
+    states = []
+    for S_ in (4, 8, 32, 64, 128):
+        Bs, Ts = 10000, 1000
+        torch.manual_seed(S_)
+        det_s = mvn.VNETDetector(S_, {"train": Ts, "val": Ts}).to(dev)
+        ws_ = [p.detach().contiguous() for p in det_s.parameters()]
+        ys = torch.randn(Bs, Ts, device=dev) * 1.5
+        decs = torch.empty_like(ys)
+        nws = int(lib.mvn_vnet_workspace_bytes(Bs, Ts, S_))
+        wss = torch.empty(max(nws, 4), dtype=torch.uint8, device=dev)
+        ms_s = max_over_ranks(event_time_ms(lambda: lib.mvn_vnet_decode_f32(mvn._lib.ptr(ys), Ts, *[mvn._lib.ptr(a) for a in ws_], mvn._lib.ptr(decs), Ts,
+                                                                           None, None, mvn._lib.ptr(wss), nws, Bs, Ts, S_, st), 10, dev))
+        flop_s = FLOP_PER_SYMBOL + 2 * 50 * (S_ - 16) + 4 * (S_ - 16)
+        ach = flop_s * Bs * Ts / (ms_s * 1e-3) / 1e12
+        states.append({"n_states": S_, "ms": ms_s, "symbols_per_s": world * Bs * Ts / (ms_s * 1e-3), "kernel": kernel_name(lib.mvn_vnet_decode_kernel_name, Bs, Ts, S_, 0),
+                       "workspace_bytes": nws,
+                       "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                                    "flop_per_symbol": flop_s}})
+        del ys, decs, wss
+    out.append({"config": "ViterbiNet at 4 / 8 / 32 / 64 / 128 states, 10 000 blocks x 1000 symbols per GPU (the fused kernel of every other trellis size)",
+                "n_gpus": world, "blocks_per_gpu": 10000, "by_states": states, "parallelism": f"block-sharded x{world}"})
+
     if not by_word:  # (profiling runs: the two VA configs only)
         return out
     # ---- configs[2] / [4]: 300 blocks by word (T = 120 + 8*2, RS(17,15)), ViterbiNet weights trained on the reference
