@@ -41,8 +41,9 @@ while time.time() < t_end:
         os.environ.pop(k, None)
     S = int(2 ** rng.randint(1, 9))
     big = rng.rand() < 0.1
-    B = int(rng.randint(6000, 9000)) if (big and S == 16) else int(rng.randint(1, 300))
-    T = int(rng.randint(1, 40)) if big else int(rng.randint(1, 200))
+    # big: the dealt kernel's rings of one (16 states) / vnet_fused_ip_kernel's launches spread over every CU and of several rounds
+    B = int(rng.randint(6000, 9000)) if (big and S == 16) else int(rng.randint(500, 6000)) if (big and 4 <= S <= 128) else int(rng.randint(1, 300))
+    T = int(rng.randint(1, 40 if S <= 32 else 12)) if big else int(rng.randint(1, 200))
     pad_y, pad_d = int(rng.randint(0, 5)), int(rng.randint(0, 5))
     if S == 16:
         os.environ["MVN_SWEEP16"] = str(rng.choice(["rows", "lds", "quad"]))
