@@ -1552,6 +1552,9 @@ void mvn_test_hooks(int64_t group_spin_limit, int32_t group_phantoms) {
     if (group_spin_limit >= 0) g_group_spin_limit.store((unsigned)group_spin_limit, std::memory_order_relaxed);
     if (group_phantoms >= 0) g_group_phantoms.store(group_phantoms, std::memory_order_relaxed);
 }
+/* The one-XCD barrier of the chunked training launches (train_groups.inc, groups_barrier's `local` branch): workgroup `k` of every
+ * trial never stores its tag, so its peers must abandon the wait (k < 0: off).  Shares the launch field of the phantom arrivals. */
+void mvn_test_hooks_skip_tag(int32_t k) { g_group_phantoms.store(k < 0 ? 0 : -(k + 1), std::memory_order_relaxed); }
 /* The dealt ViterbiNet kernel's hand-off between rings: ring `skip_ring` never publishes (-1: all do), and the waiting ring
  * gives up after `spin_limit` polls (< 0: unchanged). */
 void mvn_test_hooks_dealt(int32_t skip_ring, int64_t spin_limit) {

@@ -437,6 +437,41 @@ def test_abandoned_group_barrier_is_reported_not_silent(golden, dev, hooks_lib):
     assert bool(torch.isfinite(next(det.parameters())).all())
 
 
+def test_abandoned_one_xcd_tag_barrier_is_reported(golden, dev, hooks_lib, monkeypatch):
+    """The give-up path of the barrier a trial's workgroups use when they share an XCD (tags in its L2, train_groups.inc): one
+    workgroup of the trial never publishes its tag (test hook), the others abandon the wait after the lowered spin limit -- status
+    word set, NaN weights, MvnError from check_status -- exactly as for the device-wide counter barrier."""
+    g7 = golden("g7_by_word")
+    w = [g7[f"w{i}"] for i in range(6)]
+    T = 136
+    gen = torch.Generator(device=dev).manual_seed(5)
+    y = torch.randn(1, T, generator=gen, device=dev)
+    tx = torch.randint(0, 2, (1, T), generator=gen, device=dev).float()
+    monkeypatch.setenv("MVN_TRAIN_XCD", "1")  # a single trial's chunk workgroups on one XCD
+    mvn._lib.reload_switches()
+    name = ctypes.create_string_buffer(128)
+    assert hooks_lib.mvn_vnet_train_kernel_name(0, 0, T, 0, 16, 1 << 22, name, 128) == 0 and b"one XCD per trial" in name.value, name.value
+    hooks_lib.mvn_test_hooks_skip_tag.argtypes, hooks_lib.mvn_test_hooks_skip_tag.restype = [ctypes.c_int32], None
+    try:
+        hooks_lib.mvn_test_hooks(4000, -1)
+        hooks_lib.mvn_test_hooks_skip_tag(2)
+        det = _vnet_with(w, T, dev)
+        tr = mvn.OnlineTrainer(det, 4)
+        tr.online_training(tx, y, iterations=3, full_word=True)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(next(det.parameters())).all())
+        with pytest.raises(mvn._lib.MvnError, match="barrier"):
+            tr.check_status()
+    finally:
+        hooks_lib.mvn_test_hooks_skip_tag(-1)
+        hooks_lib.mvn_test_hooks(1 << 22, 0)
+    det = _vnet_with(w, T, dev)
+    tr = mvn.OnlineTrainer(det, 4)
+    tr.online_training(tx, y, iterations=3, full_word=True)
+    tr.check_status()
+    assert bool(torch.isfinite(next(det.parameters())).all())
+
+
 def test_two_training_launches_in_flight(golden, dev):
     """Two one-workgroup-per-chunk training calls in flight at once on two streams (each with its own workspace and barrier
     counter; 5 + 5 workgroups on a 256-CU device): results identical to running them one after the other."""
