@@ -17,6 +17,9 @@ cp $O/kernel_stats.csv $P/r05_kernel_stats.csv
 cp $O/pmc/summary.csv $P/r05_pmc_summary.csv
 cp $O/time_step.txt $P/r05_time_byword_step.txt
 cp $O/time_online_training.txt $P/r05_time_online_training.txt
+cp $O/time_online_states.txt $P/r05_time_online_states.txt
+cp $O/time_vnet_states.txt $P/r05_time_vnet_states.txt
+cp $O/time_dealt.txt $P/r05_time_dealt.txt
 cp $O/time_trials.txt $P/r05_time_trials.txt
 cp $O/train_kernels_time.csv $P/r05_train_kernels_time.csv
 cp $O/train_pmc_table.csv $P/r05_train_pmc.csv
