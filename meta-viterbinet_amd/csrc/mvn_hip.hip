@@ -1207,6 +1207,8 @@ int mvn_acs_sweep_surv_f32(const float *cost, float *dec, int64_t dec_ld, float 
     if (!valid_states(S)) return MVN_E_STATES;
     if (B == 0 || T == 0) return MVN_OK;
     if (!cost || !dec || !surv) return MVN_E_NULL;
+    if (S == 16 && sw(SW_GENERIC_SWEEP) != '1' && sweep16_quad_surv_serves(cost, dec, dec_ld, surv, T))  // the HBM-bound form (sweep16_quad.inc)
+        return launch_sweep16_quad_surv(cost, dec, dec_ld, final_metric, surv, B, T, (hipStream_t)stream);
     return launch_sweep_surv<MODE_COST>(cost, 0, nullptr, 1, dec, dec_ld, final_metric, surv, B, T, S, (hipStream_t)stream);
 }
 
@@ -1217,6 +1219,8 @@ int mvn_va_decode_surv_f32(const float *y, int64_t y_ld, const float *state_prio
     if (Bp < 1 || (B % Bp) != 0) return MVN_E_PRIORS;
     if (B == 0 || T == 0) return MVN_OK;
     if (!y || !state_priors || !dec || !surv) return MVN_E_NULL;
+    if (S == 16 && sw(SW_GENERIC_SWEEP) != '1' && va16_quad_surv_serves(dec, dec_ld, surv, T))  // 16 blocks per wave (va16_quad.inc)
+        return launch_va16_quad_surv(y, y_ld, state_priors, Bp, dec, dec_ld, final_metric, surv, B, T, (hipStream_t)stream);
     return launch_sweep_surv<MODE_VA>(y, y_ld, state_priors, Bp, dec, dec_ld, final_metric, surv, B, T, S, (hipStream_t)stream);
 }
 
@@ -1226,9 +1230,7 @@ int mvn_traceback_f32(const uint8_t *surv, const float *final_metric, float *bit
     if (!valid_states(S)) return MVN_E_STATES;
     if (B == 0 || T == 0) return MVN_OK;
     if (!surv || !final_metric || !bits) return MVN_E_NULL;
-    hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, surv, final_metric, bits,
-                       bits_ld, states, B, T, S);
-    return (int)hipGetLastError();
+    return launch_traceback(surv, final_metric, bits, bits_ld, states, B, T, S, (hipStream_t)stream);
 }
 
 int mvn_acs_sweep_kernel_name(const float *cost, const float *dec, int64_t dec_ld, int64_t B, int32_t T, int32_t S,

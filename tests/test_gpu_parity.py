@@ -1512,17 +1512,23 @@ def test_acs_block_propagates_nan_like_torch_min(oracle, dev):
 
 
 @pytest.mark.parametrize("S", [2, 4, 8, 16, 32, 64, 128, 256])
-@pytest.mark.parametrize("B,T", [(1, 1), (3, 7), (5, 64), (67, 129), (130, 33), (9, 1000)])
-def test_survivor_sweep_vs_oracle(oracle, dev, S, B, T):
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 7), (5, 64), (67, 129), (130, 33), (9, 1000), (35, 40), (300, 72)])
+def test_survivor_sweep_vs_oracle(oracle, dev, monkeypatch, S, B, T):
     """mvn_acs_sweep_surv_f32 (the optional traceback pointers of BASELINE's north_star; the reference computes and
     drops them, trellis_utils.py:30): decisions and final metrics bit for bit those of mvn_acs_sweep_f32, the survivor planes
     [B, T, max(1, S/8)] bit for bit the oracle's (= acs_block's argmin_j, pinned to G1 in test_oracle_golden), and
-    mvn_traceback_f32's path = the oracle's = the textbook Viterbi path; odd costs (a NaN, exact ties) included."""
+    mvn_traceback_f32's path = the oracle's = the textbook Viterbi path; odd costs (a NaN, exact ties) included.  At 16 states with
+    T % 4 == 0 the HBM-bound form runs (sweep16_quad_kernel<0, true, true>: round 5), otherwise -- and with MVN_GENERIC_SWEEP=1,
+    compared below -- the state-per-lane kernel; (300, 72) has a wave that meets its first odd cost in its fourth chunk (the chunk
+    is redone with torch's rule from the saved metrics) next to waves that never meet one."""
     rng = np.random.RandomState(S * 1000 + B * 10 + T)
     cost = rng.normal(0, 2, (B, T, S)).astype(np.float32)
     cost[B // 2] = np.round(cost[B // 2])  # exact ties: the first minimal index wins
     if T > 5 and B > 2:
         cost[1, 3, S - 1] = np.nan  # torch.min's index rule: the first NaN
+    if B >= 300:
+        cost[40, 55, 1] = np.inf
+        cost[41, 56, 0] = np.nan
     with np.errstate(invalid="ignore"):
         rdec, rfm, rsurv = oracle.acs_sweep_surv(cost)
         rbits, rstates = oracle.traceback(rsurv, rfm)
@@ -1535,6 +1541,11 @@ def test_survivor_sweep_vs_oracle(oracle, dev, S, B, T):
     bits, states = mvn.traceback(surv, fm, return_states=True)
     assert np.array_equal(_np(bits), rbits) and np.array_equal(_np(states), rstates)
     assert int(mvn._lib.load().mvn_survivor_bytes(B, T, S)) == surv.numel()
+    if S == 16:
+        monkeypatch.setenv("MVN_GENERIC_SWEEP", "1")
+        mvn._lib.reload_switches()
+        dec_g, fm_g, surv_g = mvn.acs_sweep_survivors(ct)
+        assert torch.equal(dec_g, dec) and torch.equal(surv_g, surv) and np.array_equal(_np(fm_g), _np(fm), equal_nan=True)
 
 
 @pytest.mark.parametrize("L", [2, 4, 8])
@@ -1556,6 +1567,43 @@ def test_va_viterbi_path_with_traceback(oracle, dev, L):
     err_running = int((dec[:, :T - L] != tx[:, :T - L]).sum().item())
     # (8 taps of exp(-0.2 k) are heavy ISI: there the maximum-likelihood path itself errs at 12 dB, a third as often as the running argmin)
     assert err_path <= err_running and (err_path <= 2 if L <= 4 else 2 * err_path < err_running), (err_path, err_running)
+
+
+@pytest.mark.parametrize("what", ["clean", "nan_y", "inf_y", "inf_prior", "nan_prior"])
+@pytest.mark.parametrize("B,T", [(40, 76), (17, 64), (300, 20)])
+def test_va_survivors_at_16_states_follow_torch_min(oracle, dev, monkeypatch, what, B, T):
+    """mvn_va_decode_surv_f32 at 16 states runs va16_quad_kernel<true, true> (16 blocks per wave, round 5), which decides by itself
+    when torch.min's NaN rule is needed (a state prior or a received sample that is not finite): decisions, final metrics and
+    survivors = the oracle's over the same costs, = the state-per-lane kernel's (MVN_GENERIC_SWEEP=1), ragged last chunk included."""
+    S = 16
+    rng = np.random.RandomState(B + T + len(what))
+    y = rng.normal(0, 1.5, (B, T)).astype(np.float32)
+    pri = rng.normal(0, 1, (1, S)).astype(np.float32)
+    if what == "nan_y":
+        y[3, T // 3] = np.nan
+    elif what == "inf_y":
+        y[B - 1, T // 2] = np.inf
+        y[2, 5] = -np.inf
+    elif what == "inf_prior":
+        pri[0, 5] = np.inf
+    elif what == "nan_prior":
+        pri[0, 9] = np.nan
+    with np.errstate(all="ignore"):
+        rdec, rfm, rsurv = oracle.acs_sweep_surv(oracle.va_costs(y, pri))
+    lib, st = mvn._lib.load(), mvn._lib.current_stream(dev)
+    yt, pt = torch.tensor(y, device=dev), torch.tensor(pri, device=dev)
+    out = {}
+    for generic in ("0", "1"):
+        monkeypatch.setenv("MVN_GENERIC_SWEEP", generic)
+        mvn._lib.reload_switches()
+        dec, fm = torch.full((B, T), 7.0, device=dev), torch.empty(B, S, device=dev)
+        surv = torch.zeros(B, T, 2, dtype=torch.uint8, device=dev)
+        assert lib.mvn_va_decode_surv_f32(mvn._lib.ptr(yt), T, mvn._lib.ptr(pt), 1, mvn._lib.ptr(dec), T, mvn._lib.ptr(fm), mvn._lib.ptr(surv),
+                                          B, T, S, st) == 0
+        assert np.array_equal(_np(dec), rdec), (what, generic)
+        assert np.array_equal(_np(fm), rfm, equal_nan=True), (what, generic)
+        assert np.array_equal(_np(surv), rsurv), (what, generic)
+        out[generic] = surv
 
 
 SWEEP_VARIANTS = [(4, ""), (8, ""), (16, "rows"), (16, "lds"), (16, "quad"), (16, "inplace"), (16, "generic"), (16, "unaligned"),
