@@ -208,9 +208,17 @@ def run_configs(dev, rank, world, all_reduce, backend, weights, by_word=True):
         all_reduce(c3)
     ser3, fer3 = mvn.rates_from_counters(c3)
     k3 = kernel_name(lib.mvn_va_decode_kernel_name, B3, T3, 256)
+    # the same Monte-Carlo point in ONE launch, words generated inside the detector (mvn_va_montecarlo_f32: no tx, y, decisions in HBM)
+    mc_seed = 3450002 + 17 * rank
+    c3f = mvn.va_monte_carlo(va8, B3, SNR_DB, GAMMA, dev, mc_seed)
+    ms3f = max_over_ranks(event_time_ms(lambda: mvn.va_monte_carlo(va8, B3, SNR_DB, GAMMA, dev, mc_seed, counters=c3f), 3, dev))
     out.append({"config": "BASELINE configs[3]: VA L=8 (256 states), 10^6 blocks x 1000 symbols over 8 GPUs = 125 000 blocks per GPU",
                 "n_gpus": world, "blocks_per_gpu": B3, "ms": ms3, "symbols_per_s": world * B3 * T3 / (ms3 * 1e-3),
                 "ser": ser3, "fer": fer3, "frames": int(c3[3].item()), "kernel": k3, "roofline": valu_roofline(k3, B3, T3, 256, ms3),
+                "fused_monte_carlo": {"kernel": "va256_mc_kernel", "ms": ms3f, "symbols_per_s": world * B3 * T3 / (ms3f * 1e-3),
+                                      "hbm_bytes_per_symbol": 0, "vs_generate_decode_count_bytes_per_symbol": 12,
+                                      "what": "generate + detect + count in one launch (words never in memory); counters equal the three launches' "
+                                              "on the same seed (tests/test_gpu_parity.py::test_va_monte_carlo_equals_the_three_launches)"},
                 "parallelism": f"block-sharded x{world}, one all-reduce of int64[4] counters"})
     del tx3, y3, dec3
 

@@ -52,7 +52,7 @@ typedef void *mvn_stream_t; /* hipStream_t */
 
 #define MVN_E_BARRIER (-7)   /* (status words only) a training launch abandoned its device-wide barrier */
 
-#define MVN_ABI_VERSION 6 /* 6: workspace arguments on mvn_vnet_decode_count_f32 (the dealt 16-state kernel's hand-off lines), + the survivor / traceback entry points; 5: + mvn_vnet_train_kernel_name, mvn_va_byword_step_f32; 4: + trial-batched training / by-word step, status words; 3: training with a workspace; 2: kernel-name queries */
+#define MVN_ABI_VERSION 6 /* 6: workspace arguments on mvn_vnet_decode_count_f32 (the dealt 16-state kernel's hand-off lines), + the survivor / traceback entry points and mvn_va_montecarlo_f32; 5: + mvn_vnet_train_kernel_name, mvn_va_byword_step_f32; 4: + trial-batched training / by-word step, status words; 3: training with a workspace; 2: kernel-name queries */
 
 /* ABI version of the loaded library (== MVN_ABI_VERSION). */
 int mvn_version(void);
@@ -385,6 +385,19 @@ int mvn_isi_awgn_transmit(const float *bits, int64_t ld_bits, int32_t K, const v
  */
 int mvn_generate_words_f32(float *tx, int64_t tx_ld, float *y, int64_t y_ld, const double *h, int64_t Bh, double sigma,
                            uint64_t seed, int64_t B, int32_t T, int32_t L, mvn_stream_t stream);
+
+/*
+ * One uncoded Monte-Carlo point of the classical Viterbi detector in ONE launch: the words of mvn_generate_words_f32 (same seed ->
+ * the same bits and samples, bit for bit) are generated inside the detector of mvn_va_decode_f32 and the decisions compared with
+ * the generated bits on the spot -- Trainer.single_eval_at_point, python_code/trainers/trainer.py:222-241 (draw words,
+ * detector(rx, 'val'), calculate_error_rates) with no tx, y or decisions in memory ("fused into the decode kernel so y
+ * never touches HBM").  counters[0..3] += {bit_errors, bits, frame_errors, frames} over B words of T symbols, exactly the counters
+ * of mvn_generate_words_f32 -> mvn_va_decode_f32 -> mvn_count_errors(K = T).
+ *   h [Bh,L] float64 taps (row b % Bh), sigma = 10^(-snr/20); state_priors [Bp,S] (row b % Bp: VADetector.compute_state_priors);
+ *   S = 16 or 256 (MVN_E_STATES otherwise: run the three launches); counters: device int64[4], accumulated into.
+ */
+int mvn_va_montecarlo_f32(const double *h, int64_t Bh, double sigma, uint64_t seed, const float *state_priors, int64_t Bp,
+                          int64_t *counters, int64_t B, int32_t T, int32_t L, int32_t S, mvn_stream_t stream);
 
 /*
  * Reed-Solomon outer code, batched over words; bits are fp32 {0,1}, 8 per GF(2^8)

@@ -60,6 +60,7 @@ SIGNATURES = {
     "mvn_isi_awgn_transmit": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _i64, ctypes.c_double, _vp, _i64, _i64,
                                              _i32, _i32, _vp]),
     "mvn_generate_words_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, ctypes.c_double, ctypes.c_uint64, _i64, _i32, _i32, _vp]),
+    "mvn_va_montecarlo_f32": (ctypes.c_int, [_vp, _i64, ctypes.c_double, ctypes.c_uint64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
     "mvn_rs_decode_bits_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
     "mvn_rs_encode_bits_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
     "mvn_count_errors": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp]),

@@ -440,6 +440,7 @@ int current_device_cus();  // CUs of the current device, cached per device (defi
 #include "maml_train.inc"
 #include "train_groups.inc"
 #include "word_gen.inc"
+#include "va_montecarlo.inc"
 
 // -------------------------------------------------------------------------------------------
 // metrics.py:7-17 as integer counters.  One wave per row, block-level reduction, one atomic
@@ -1592,6 +1593,17 @@ int mvn_generate_words_f32(float *tx, int64_t tx_ld, float *y, int64_t y_ld, con
     hipLaunchKernelGGL(generate_words_kernel, dim3((unsigned)((n + kGenThreads - 1) / kGenThreads)), dim3(kGenThreads), 0,
                        (hipStream_t)stream, tx, tx_ld, y, y_ld, h, Bh, sigma, (uint32_t)seed, (uint32_t)(seed >> 32), B, T, L);
     return (int)hipGetLastError();
+}
+
+int mvn_va_montecarlo_f32(const double *h, int64_t Bh, double sigma, uint64_t seed, const float *state_priors, int64_t Bp,
+                          int64_t *counters, int64_t B, int32_t T, int32_t L, int32_t S, mvn_stream_t stream) {
+    if (B < 0 || T < 0 || L < 1 || L > 16 || Bh < 1) return MVN_E_DIMS;
+    if (S != 16 && S != 256) return MVN_E_STATES;  // the two classical-Viterbi trellises of BASELINE (configs[0], configs[3])
+    if (Bp < 1) return MVN_E_PRIORS;
+    if (!counters) return MVN_E_NULL;
+    if (B == 0 || T == 0) return MVN_OK;
+    if (!h || !state_priors) return MVN_E_NULL;
+    return launch_va_montecarlo(h, Bh, sigma, seed, state_priors, Bp, (unsigned long long *)counters, B, T, L, S, (hipStream_t)stream);
 }
 
 int mvn_rs_decode_bits_f32(const float *rx_bits, int64_t ld_in, float *msg_bits, int64_t ld_out, int32_t *status,

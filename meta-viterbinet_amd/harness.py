@@ -60,6 +60,32 @@ def synthetic_words(n_words: int, block_length: int, memory_length: int, snr: fl
     return tx, y.float()
 
 
+def va_monte_carlo(detector, n_words: int, snr: float, gamma: float, device, seed: int, counters: Optional[torch.Tensor] = None):
+    """One uncoded Monte-Carlo point of the classical Viterbi detector in ONE launch (mvn_va_montecarlo_f32): what
+    Trainer.single_eval_at_point does (trainer.py:222-241: draw the words, detector(rx, 'val'), calculate_error_rates), with the words
+    of synthetic_words(..., seed) generated inside the detector and compared there -- no tx, y or decisions in device memory (at
+    BASELINE configs[3], 10^6 blocks x 1000 symbols, those are 12 GB).  16 or 256 states; the words' channel is the detector's
+    (`_estimate_all`: row b % val_words for word b, like its state priors).  Returns int64[4] counters {bit_errors, bits,
+    frame_errors, frames} on `device` (accumulated into `counters` when given): the same numbers as
+    count_errors(detector(y, 'val', snr, gamma), tx) over (tx, y) = synthetic_words(n_words, T, L, snr, gamma, device, seed)."""
+    from . import _lib
+
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.MvnError("va_monte_carlo runs on an MI355X (ROCm) device only")
+    T, L, S = detector.transmission_length, detector.memory_length, detector.n_states
+    h = torch.as_tensor(np.ascontiguousarray(detector._estimate_all(gamma, "val"), dtype=np.float64).reshape(-1, L), device=dev)
+    pri = detector._priors_table(torch.empty(0, device=dev), gamma, "val", None)
+    if counters is None:
+        counters = torch.zeros(4, dtype=torch.int64, device=dev)
+    sigma = (10 ** (snr / 10)) ** (-0.5)  # channel.py:23,31
+    with torch.cuda.device(dev):
+        rc = _lib.load().mvn_va_montecarlo_f32(_lib.ptr(h), h.shape[0], float(sigma), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(pri),
+                                               pri.shape[0], _lib.ptr(counters), n_words, T, L, S, _lib.current_stream(dev))
+    _lib.check(rc, "mvn_va_montecarlo_f32")
+    return counters
+
+
 def _gpu_counter(detected: torch.Tensor, tx: torch.Tensor, rows: Optional[torch.Tensor]) -> torch.Tensor:
     return _metrics.count_errors(detected, tx, rows)
 

@@ -1606,6 +1606,36 @@ def test_va_survivors_at_16_states_follow_torch_min(oracle, dev, monkeypatch, wh
         out[generic] = surv
 
 
+@pytest.mark.parametrize("L,B,T", [(4, 1, 1), (4, 37, 1000), (4, 300, 72), (4, 70, 141), (4, 6500, 40), (8, 1, 7), (8, 9, 1000), (8, 23, 130),
+                                   (8, 130, 64)])
+@pytest.mark.parametrize("what", ["static", "fading", "inf_prior"])
+def test_va_monte_carlo_equals_the_three_launches(dev, L, B, T, what):
+    """mvn_va_montecarlo_f32 (round 5; SURVEY 8f#1 "fused into the decode kernel so y never touches HBM"): the words generated
+    INSIDE the classical detector and compared there.  Its four counters equal those of mvn_generate_words_f32 -> mvn_va_decode_f32
+    -> mvn_count_errors on the same seed exactly -- 16 and 256 states, ragged chunks, a per-word (fading) channel table, and a
+    non-finite state prior (the fused kernel runs torch.min's rule itself, the three launches take the guard launch)."""
+    S = 2 ** L
+    fading = what == "fading" and L == 4  # (the reference's fading taps exist for memory 4: channel_estimation.py)
+    W = B if fading and B <= 300 else 1
+    if fading and W == 1:
+        pytest.skip("per-word channel rows: val_words = B")
+    det = mvn.VADetector(S, L, T, W, "ISI_AWGN", 0, fading, 1, CC)
+    snr, gamma, seed = 9.0, 0.2, 1234 + B
+    if what == "inf_prior":
+        tab = det._priors_table(torch.empty(0, device=dev), gamma, "val", None)
+        tab[0, 3] = float("inf")  # (the cached table: both routes read it)
+    h = det._estimate_all(gamma, "val")
+    tx, y = mvn.generate_words(B, T, h, snr, L, dev, seed)
+    want = mvn.count_errors(det(y, "val", snr, gamma), tx)
+    got = mvn.va_monte_carlo(det, B, snr, gamma, dev, seed)
+    assert got.tolist() == want.tolist(), (got.tolist(), want.tolist())
+    assert got[1].item() == B * T and got[3].item() == B and (what == "inf_prior" or B * T < 1000 or 0 < got[0].item() < B * T // 4)
+    again = mvn.va_monte_carlo(det, B, snr, gamma, dev, seed, counters=got.clone())  # accumulates
+    assert again.tolist() == [2 * v for v in want.tolist()]
+    other = mvn.va_monte_carlo(det, B, snr, gamma, dev, seed + 1)
+    assert other[1].item() == B * T and (B * T < 1000 or other[0].item() != want[0].item())  # another seed, other words
+
+
 SWEEP_VARIANTS = [(4, ""), (8, ""), (16, "rows"), (16, "lds"), (16, "quad"), (16, "inplace"), (16, "generic"), (16, "unaligned"),
                   (32, ""), (64, ""), (64, "generic"), (128, ""), (256, ""), (2, "")]
 
