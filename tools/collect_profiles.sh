@@ -20,6 +20,8 @@ cp $O/time_online_training.txt $P/r05_time_online_training.txt
 cp $O/time_online_states.txt $P/r05_time_online_states.txt
 cp $O/time_vnet_states.txt $P/r05_time_vnet_states.txt
 cp $O/time_dealt.txt $P/r05_time_dealt.txt
+cp $O/time_survivors.txt $P/r05_time_survivors.txt
+cp $O/time_montecarlo.txt $P/r05_time_montecarlo.txt
 cp $O/time_trials.txt $P/r05_time_trials.txt
 cp $O/train_kernels_time.csv $P/r05_train_kernels_time.csv
 cp $O/train_pmc_table.csv $P/r05_train_pmc.csv

@@ -42,6 +42,8 @@ python3 tools/time_online.py 2>&1 | grep -v amdgpu.ids > $O/time_online_training
 python3 tools/time_online_states.py 2>&1 | grep -v amdgpu.ids > $O/time_online_states.txt
 python3 tools/time_vnet_states.py 4,10000 8,10000 32,10000 64,10000 128,4000 128,10000 256,2000 4,1000 128,1000 2>&1 | grep -v amdgpu.ids > $O/time_vnet_states.txt
 python3 tools/time_dealt.py 2>&1 | grep -v amdgpu.ids > $O/time_dealt.txt
+python3 tools/time_survivors.py 2>&1 | grep -v amdgpu.ids > $O/time_survivors.txt
+python3 tools/time_montecarlo.py 2>&1 | grep -v amdgpu.ids > $O/time_montecarlo.txt
 timeout -k 10 200 python3 tools/fuzz_parity.py 120 2>&1 | grep -v amdgpu.ids | tail -5 > $O/fuzz_parity.txt
 rm -rf $O/kt $O/kh $O/pmc/FETCH_SIZE $O/pmc/WRITE_SIZE $O/pmc/TCC* $O/pmc/SQ* $O/pmc_train/pass*/ $O/pmc_head*/pass*/ $O/pmc_va256/pass*/
 ls $O $O/pmc
