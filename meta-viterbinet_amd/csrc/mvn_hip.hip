@@ -787,10 +787,11 @@ bool generic_sweep_forced() { return sw(SW_GENERIC_SWEEP) == '1'; }
 
 // Which kernel serves a sweep: ONE decision function used by the dispatcher and by the mvn_*_kernel_name queries, so the
 // name a caller is told is the kernel that runs (same environment switches, same alignment fall-backs).
-enum SweepKind { SK_GENERIC, SK_VA256_WAVE, SK_VA_INPLACE, SK_SWEEP_INPLACE, SK_S16_QUAD, SK_S16_LDS, SK_S16_ROWS, SK_VA16_QUAD, SK_VA16_TILE };
+enum SweepKind { SK_GENERIC, SK_VA256_WAVE, SK_VA_INPLACE, SK_SWEEP_INPLACE, SK_S16_QUAD, SK_S16_LDS, SK_S16_ROWS, SK_VA16_QUAD, SK_VA16_TILE,
+                 SK_VA16_SPLIT };
 
 template <int MODE>
-SweepKind plan_sweep(const void *src, const void *dec, int64_t dec_ld, int64_t B, int S) {
+SweepKind plan_sweep(const void *src, const void *dec, int64_t dec_ld, int64_t B, int S, int T = 1 << 30) {
     const bool generic = generic_sweep_forced();
     if constexpr (MODE == MODE_VA) {
         // classical VA: the lane-bits x register-bits in-place kernel serves every S >= 4 except S = 16, which has its
@@ -798,10 +799,11 @@ SweepKind plan_sweep(const void *src, const void *dec, int64_t dec_ld, int64_t B
         // (and S = 256, one block per wave with scalar decisions; MVN_VA256=inplace keeps the family kernel there)
         if (S == 256 && !generic && sw(SW_VA256) != 'i') return SK_VA256_WAVE;
         if (S >= 4 && !generic && (S != 16 || sw(SW_VA_INPLACE) == '1')) return SK_VA_INPLACE;
-        if (S == 16 && !generic) {  // MVN_VA16 = "rows" | "quad" | "tile" pins a variant (A/B, tests); default by size:
-            const char e = sw(SW_VA16);  // one wave per block below 6 000 blocks, 16 blocks per wave from there on
+        if (S == 16 && !generic) {  // MVN_VA16 = "rows" | "quad" | "tile" | "split" pins a variant (A/B, tests); default by size:
+            const char e = sw(SW_VA16);  // four waves per block for a few hundred short blocks, one wave per block below 6 000, 16 blocks per wave from there on
             if (e == 'r' || e == 'q' || e == 't') return e == 'q' ? SK_VA16_QUAD : e == 't' ? SK_VA16_TILE : SK_S16_ROWS;
-            return B >= kVaQuadMinBlocks ? SK_VA16_QUAD : SK_VA16_TILE;
+            if (e == 's') return T <= kVaSplitMaxT ? SK_VA16_SPLIT : SK_VA16_TILE;
+            return B >= kVaQuadMinBlocks ? SK_VA16_QUAD : va16_split_serves(B, T) ? SK_VA16_SPLIT : SK_VA16_TILE;
         }
         return SK_GENERIC;
     } else {
@@ -840,6 +842,7 @@ void sweep_kernel_name(SweepKind k, int S, const void *dec, int64_t dec_ld, char
         case SK_S16_ROWS: snprintf(name, n, "sweep16_rows_kernel<%d>", MODE); break;
         case SK_VA16_QUAD: snprintf(name, n, "va16_quad_kernel"); break;
         case SK_VA16_TILE: snprintf(name, n, "va16_tile_kernel"); break;
+        case SK_VA16_SPLIT: snprintf(name, n, "va16_split_kernel"); break;
         default: snprintf(name, n, "sweep_kernel<%d, %d>", S, MODE); break;
     }
 }
@@ -849,7 +852,7 @@ template <int MODE>
 int dispatch_sweep(const float *src, int64_t src_ld, const float *priors, int64_t Bp, float *dec, int64_t dec_ld,
                    float *final_metric, int64_t B, int T, int S, hipStream_t st, const GuardWeights *gw = nullptr) {
     int rc = -1;
-    const SweepKind kind = plan_sweep<MODE>(src, dec, dec_ld, B, S);
+    const SweepKind kind = plan_sweep<MODE>(src, dec, dec_ld, B, S, T);
     switch (kind) {
         case SK_VA256_WAVE:
             if constexpr (MODE == MODE_VA) rc = launch_va256_wave(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
@@ -862,6 +865,12 @@ int dispatch_sweep(const float *src, int64_t src_ld, const float *priors, int64_
             break;
         case SK_VA16_TILE:  // (strict by itself: va16_tile.inc)
             if constexpr (MODE == MODE_VA) return launch_va16_tile(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
+            break;
+        case SK_VA16_SPLIT:  // (strict by itself too; a launch that cannot have its LDS falls back to one wave per block)
+            if constexpr (MODE == MODE_VA) {
+                const int rs = launch_va16_split(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st);
+                return rs < 0 ? launch_va16_tile(src, src_ld, priors, Bp, dec, dec_ld, final_metric, B, T, st) : rs;
+            }
             break;
         case SK_SWEEP_INPLACE:
             if constexpr (MODE != MODE_VA) rc = launch_sweep_inplace<MODE>(src, dec, dec_ld, final_metric, B, T, S, st);
@@ -1247,7 +1256,7 @@ int mvn_va_decode_kernel_name(int64_t B, int32_t T, int32_t S, char *name, int32
     (void)T;
     if (!valid_states(S)) return MVN_E_STATES;
     if (!name || name_len < 1) return MVN_E_NULL;
-    sweep_kernel_name<MODE_VA>(plan_sweep<MODE_VA>(nullptr, nullptr, 0, B, S), S, nullptr, 0, name, (size_t)name_len);
+    sweep_kernel_name<MODE_VA>(plan_sweep<MODE_VA>(nullptr, nullptr, 0, B, S, T), S, nullptr, 0, name, (size_t)name_len);
     return MVN_OK;
 }
 

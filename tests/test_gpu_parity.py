@@ -300,10 +300,10 @@ def test_sweep16_rows_and_generic_paths(oracle, dev, monkeypatch, B, T):
     rdec, rfm = oracle.acs_sweep(cost)
     vdec, vfm = oracle.va_decode(y, pri)
     ct, yt, pt = torch.tensor(cost, device=dev), torch.tensor(y, device=dev), torch.tensor(pri, device=dev)
-    for generic, variant, va in (("0", "lds", "tile"), ("0", "rows", "rows"), ("0", "quad", "quad"), ("1", "lds", "rows")):
+    for generic, variant, va in (("0", "lds", "tile"), ("0", "rows", "rows"), ("0", "quad", "quad"), ("1", "lds", "rows"), ("0", "lds", "split")):
         monkeypatch.setenv("MVN_GENERIC_SWEEP", generic)
         monkeypatch.setenv("MVN_SWEEP16", variant)  # LDS-DMA streaming vs register-prefetch row sweep
-        monkeypatch.setenv("MVN_VA16", va)  # one block per wave (default below 6 000 blocks) / 4 / 16 blocks per wave
+        monkeypatch.setenv("MVN_VA16", va)  # one block per wave (default below 6 000 blocks) / 4 / 16 blocks per wave / 4 waves per block
         dec, fm = mvn.acs_sweep(ct, return_final=True)
         assert np.array_equal(_np(dec), rdec) and np.array_equal(_np(fm), rfm), generic
         d2 = torch.zeros_like(yt)
@@ -334,7 +334,9 @@ def test_sweep16_quad_variant(oracle, dev, monkeypatch):
     assert name(None, None, 52, B, T, S) == (0, "sweep16_rows_kernel<0>")
     monkeypatch.delenv("MVN_SWEEP16")
     assert (lib.mvn_va_decode_kernel_name(125000, 1000, 256, buf, 64), buf.value) == (0, b"va256_wave_kernel")
-    assert (lib.mvn_va_decode_kernel_name(100, 1000, 16, buf, 64), buf.value) == (0, b"va16_tile_kernel")
+    assert (lib.mvn_va_decode_kernel_name(100, 1000, 16, buf, 64), buf.value) == (0, b"va16_split_kernel")  # four waves per block
+    assert (lib.mvn_va_decode_kernel_name(100, 2000, 16, buf, 64), buf.value) == (0, b"va16_tile_kernel")  # T > 1024
+    assert (lib.mvn_va_decode_kernel_name(2000, 1000, 16, buf, 64), buf.value) == (0, b"va16_tile_kernel")  # more than two blocks per CU
     assert (lib.mvn_va_decode_kernel_name(10000, 1000, 16, buf, 64), buf.value) == (0, b"va16_quad_kernel")
     assert (lib.mvn_vnet_decode_kernel_name(10000, 1000, 16, 0, buf, 64), buf.value) == (0, b"vnet16_dealt_kernel<false> rings of 1")
     assert (lib.mvn_vnet_decode_kernel_name(1250, 1000, 16, 0, buf, 64), buf.value) == (0, b"vnet16_dealt_kernel<false> rings of 8")
@@ -1459,7 +1461,7 @@ def test_nonfinite_samples_like_reference(oracle, dev, monkeypatch):
     assert np.array_equal(_np(det(yt, "val")), rdec)
     assert np.all(rdec[1, 22:] == 0) and np.all(rdec[2, 2:] == 0)  # everything after a NaN sample decodes to 0
     pt = torch.tensor(pri, device=dev)
-    for variant in ("rows", "quad", "tile"):
+    for variant in ("rows", "quad", "tile", "split"):
         monkeypatch.setenv("MVN_VA16", variant)
         d2 = torch.zeros_like(yt)
         rc = mvn._lib.load().mvn_va_decode_f32(mvn._lib.ptr(yt), T, mvn._lib.ptr(pt), 1, mvn._lib.ptr(d2), T, None, B, T, S,
@@ -1737,7 +1739,7 @@ def test_vnet_partial_nan_follows_torch_min(oracle, dev, monkeypatch, S, env, wh
         assert np.isnan(rfm).all()  # the NaN state reaches every state within L steps under torch.min
 
 
-VA_NAN_ROUTES = [(16, {"MVN_VA16": "tile"}), (16, {"MVN_VA16": "rows"}), (16, {"MVN_VA16": "quad"}), (16, {"MVN_VA_INPLACE": "1"}),
+VA_NAN_ROUTES = [(16, {"MVN_VA16": "tile"}), (16, {"MVN_VA16": "split"}), (16, {"MVN_VA16": "rows"}), (16, {"MVN_VA16": "quad"}), (16, {"MVN_VA_INPLACE": "1"}),
                  (16, {"MVN_GENERIC_SWEEP": "1"}), (2, {}), (4, {}), (8, {}), (32, {}), (64, {}), (128, {}), (256, {}),
                  (256, {"MVN_VA256": "inplace"})]
 

@@ -47,7 +47,7 @@ while time.time() < t_end:
     pad_y, pad_d = int(rng.randint(0, 5)), int(rng.randint(0, 5))
     if S == 16:
         os.environ["MVN_SWEEP16"] = str(rng.choice(["rows", "lds", "quad"]))
-        os.environ["MVN_VA16"] = str(rng.choice(["rows", "quad", "tile"]))
+        os.environ["MVN_VA16"] = str(rng.choice(["rows", "quad", "tile", "split"]))
         os.environ["MVN_FUSEDN"] = str(rng.choice(["2", "4"]))
         if rng.rand() < 0.5:
             os.environ["MVN_COOP"] = str(rng.choice(["0", "1"]))

@@ -41,7 +41,7 @@ valu = {
              "bench.py's configs entries; SQ_INSTS_VALU includes the MFMA instructions.",
     "csrc_sha16": sha,
 }
-shapes = {"sweep16_rows_kernel<2>": (100, 1000, 16), "va16_tile_kernel": (100, 1000, 16), "va_inplace_kernel<6>": (125000, 1000, 256),
+shapes = {"sweep16_rows_kernel<2>": (100, 1000, 16), "va16_tile_kernel": (100, 1000, 16), "va16_split_kernel": (100, 1000, 16), "va_inplace_kernel<6>": (125000, 1000, 256),
           "va256_wave_kernel": (125000, 1000, 256)}
 for k in sorted(rows):
     c = rows[k]

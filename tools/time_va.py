@@ -29,11 +29,11 @@ for L, B in cases:
         assert rc == 0
 
     ref = None
-    for variant in (["rows", "quad", "tile", "tmpl"] if S == 16 else ["wave", "tmpl", "generic"] if S == 256 else ["tmpl", "generic"] if S >= 4 else [""]):
+    for variant in (["rows", "quad", "tile", "split", "tmpl"] if S == 16 else ["wave", "tmpl", "generic"] if S == 256 else ["tmpl", "generic"] if S >= 4 else [""]):
         os.environ.pop("MVN_VA_INPLACE", None)
         os.environ["MVN_VA256"] = "" if variant == "wave" else "inplace"
         os.environ.pop("MVN_GENERIC_SWEEP", None)
-        if variant in ("rows", "quad", "tile"):
+        if variant in ("rows", "quad", "tile", "split"):
             os.environ["MVN_VA16"] = variant
         elif variant == "tmpl":
             os.environ["MVN_VA_INPLACE"] = "1"
