@@ -418,6 +418,7 @@ int launch_mlp(const float *y, int64_t y_ld, int T, int64_t N, const float *W1, 
 }
 
 int current_device_cus();  // CUs of the current device, cached per device (defined below the kernels)
+int ensure_dynamic_lds(const void *fn, size_t bytes);  // raises a kernel's dynamic-LDS limit once per function and device (below)
 
 #include "sweep_surv.inc"
 
