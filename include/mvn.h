@@ -52,7 +52,7 @@ typedef void *mvn_stream_t; /* hipStream_t */
 
 #define MVN_E_BARRIER (-7)   /* (status words only) a training launch abandoned its device-wide barrier */
 
-#define MVN_ABI_VERSION 6 /* 6: workspace arguments on mvn_vnet_decode_count_f32 (the dealt 16-state kernel's hand-off lines), + the survivor / traceback entry points and mvn_va_montecarlo_f32; 5: + mvn_vnet_train_kernel_name, mvn_va_byword_step_f32; 4: + trial-batched training / by-word step, status words; 3: training with a workspace; 2: kernel-name queries */
+#define MVN_ABI_VERSION 6 /* 6: workspace arguments on mvn_vnet_decode_count_f32 (the dealt 16-state kernel's hand-off lines), + the survivor / traceback entry points (incl. mvn_vnet_decode_surv_f32) and mvn_va_montecarlo_f32; 5: + mvn_vnet_train_kernel_name, mvn_va_byword_step_f32; 4: + trial-batched training / by-word step, status words; 3: training with a workspace; 2: kernel-name queries */
 
 /* ABI version of the loaded library (== MVN_ABI_VERSION). */
 int mvn_version(void);
@@ -80,6 +80,18 @@ int mvn_acs_block_f32(const float *in_prob, const float *llrs, float *out, int64
  */
 int mvn_acs_sweep_f32(const float *cost, float *dec, int64_t dec_ld, float *final_metric,
                       int64_t B, int32_t T, int32_t S, mvn_stream_t stream);
+
+/*
+ * The ViterbiNet detector with survivors (round 5): mvn_vnet_decode_f32's decisions and final metrics -- the same bits -- plus the
+ * survivor planes of its sweep (branch cost = -logit, python_code/detectors/VNET/vnet_detector.py:57; acs_block's second return value,
+ * utils/trellis_utils.py:30), so that mvn_traceback_f32 yields the maximum-likelihood path through the learned branch metrics -- the
+ * textbook ViterbiNet decision, where the reference decides from a running argmin.  Runs the two-kernel route: the logits of as
+ * many blocks as fit `workspace` (at least T*S*4 bytes, 16-byte aligned; B*T*S*4 for one pass), then the survivor sweep over them.
+ *   surv [B, T, max(1, S/8)] as for mvn_acs_sweep_surv_f32.
+ */
+int mvn_vnet_decode_surv_f32(const float *y, int64_t y_ld, const float *W1, const float *b1, const float *W2, const float *b2,
+                             const float *W3, const float *b3, float *dec, int64_t dec_ld, float *final_metric, uint8_t *surv,
+                             void *workspace, size_t workspace_bytes, int64_t B, int32_t T, int32_t S, mvn_stream_t stream);
 
 /*
  * The same two sweeps WITH survivor (traceback) pointers -- optional: the reference computes them and drops them (acs_block

@@ -1219,7 +1219,7 @@ int mvn_acs_sweep_surv_f32(const float *cost, float *dec, int64_t dec_ld, float 
     if (B == 0 || T == 0) return MVN_OK;
     if (!cost || !dec || !surv) return MVN_E_NULL;
     if (S == 16 && sw(SW_GENERIC_SWEEP) != '1' && sweep16_quad_surv_serves(cost, dec, dec_ld, surv, T))  // the HBM-bound form (sweep16_quad.inc)
-        return launch_sweep16_quad_surv(cost, dec, dec_ld, final_metric, surv, B, T, (hipStream_t)stream);
+        return launch_sweep16_quad_surv<MODE_COST>(cost, dec, dec_ld, final_metric, surv, B, T, (hipStream_t)stream);
     return launch_sweep_surv<MODE_COST>(cost, 0, nullptr, 1, dec, dec_ld, final_metric, surv, B, T, S, (hipStream_t)stream);
 }
 
@@ -1233,6 +1233,37 @@ int mvn_va_decode_surv_f32(const float *y, int64_t y_ld, const float *state_prio
     if (S == 16 && sw(SW_GENERIC_SWEEP) != '1' && va16_quad_surv_serves(dec, dec_ld, surv, T))  // 16 blocks per wave (va16_quad.inc)
         return launch_va16_quad_surv(y, y_ld, state_priors, Bp, dec, dec_ld, final_metric, surv, B, T, (hipStream_t)stream);
     return launch_sweep_surv<MODE_VA>(y, y_ld, state_priors, Bp, dec, dec_ld, final_metric, surv, B, T, S, (hipStream_t)stream);
+}
+
+int mvn_vnet_decode_surv_f32(const float *y, int64_t y_ld, const float *W1, const float *b1, const float *W2, const float *b2,
+                             const float *W3, const float *b3, float *dec, int64_t dec_ld, float *final_metric, uint8_t *surv,
+                             void *workspace, size_t workspace_bytes, int64_t B, int32_t T, int32_t S, mvn_stream_t stream) {
+    if (B < 0 || T < 0 || dec_ld < T || y_ld < T) return MVN_E_DIMS;
+    if (!valid_states(S)) return MVN_E_STATES;
+    if (B == 0 || T == 0) return MVN_OK;
+    if (!y || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !dec || !surv || !workspace) return MVN_E_NULL;
+    // the logits of a slice of blocks in the workspace (mlp_kernel: the reference's logits bit for bit), then the sweep over them
+    // with branch cost -logit (vnet_detector.py:57) and the survivors kept; torch.min's rule inside the sweeps (odd costs)
+    hipStream_t st = (hipStream_t)stream;
+    const size_t per_block = (size_t)T * (size_t)S * sizeof(float);
+    int64_t slice = (int64_t)(workspace_bytes / per_block);
+    if (slice < 1 || (reinterpret_cast<uintptr_t>(workspace) & 15)) return MVN_E_WORKSPACE;
+    if (slice > B) slice = B;
+    const int SB = S >= 8 ? S / 8 : 1;
+    float *lg = (float *)workspace;
+    for (int64_t b0 = 0; b0 < B; b0 += slice) {
+        const int64_t nb = (B - b0 < slice) ? B - b0 : slice;
+        int rc = launch_mlp(y + b0 * y_ld, y_ld, T, nb * T, W1, b1, W2, b2, W3, b3, lg, S, st);
+        if (rc) return rc;
+        float *d = dec + b0 * dec_ld, *fm = final_metric ? final_metric + b0 * S : nullptr;
+        unsigned char *sv = surv + (size_t)b0 * T * SB;
+        if (S == 16 && sw(SW_GENERIC_SWEEP) != '1' && sweep16_quad_surv_serves(lg, d, dec_ld, sv, T))
+            rc = launch_sweep16_quad_surv<MODE_NEGLOGIT>(lg, d, dec_ld, fm, sv, nb, T, st);
+        else
+            rc = launch_sweep_surv<MODE_NEGLOGIT>(lg, 0, nullptr, 1, d, dec_ld, fm, sv, nb, T, S, st);
+        if (rc) return rc;
+    }
+    return MVN_OK;
 }
 
 int mvn_traceback_f32(const uint8_t *surv, const float *final_metric, float *bits, int64_t bits_ld, int32_t *states, int64_t B,

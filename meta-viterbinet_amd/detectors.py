@@ -276,6 +276,37 @@ class VNETDetector(nn.Module):
         return out.reshape(tuple(y.shape) + (self.n_states,))
 
 
+def _vnet_viterbi_path(self, y: torch.Tensor, return_all: bool = False, var=None):
+    """ViterbiNet detection with survivor-path traceback: the maximum-likelihood path through the learned branch metrics (cost =
+    -logit, vnet_detector.py:57) -- the textbook ViterbiNet decision, NOT what the reference's forward(y, 'val') returns (it decides
+    every symbol from a running argmin and drops acs_block's survivor indices, vnet_detector.py:55-57).  The same
+    logits and the same sweep with the survivors kept (mvn_vnet_decode_surv_f32), then mvn_traceback_f32 from the best final
+    metric.  Returns bits [B, y.shape[1]] (columns >= transmission_lengths['val'] zero), or with return_all (bits, running
+    decisions = forward(y,'val'), final metrics, survivors).  var: the six weight arrays (META_VNETDetector's calling form)."""
+    from .trellis import traceback
+
+    _lib.require_gpu_tensor(y, "y")
+    yc = _as_f32(y)
+    B, Ty = yc.shape
+    T, S = self.transmission_lengths["val"], self.n_states
+    _check_T(T, yc)
+    w = _weights_on(self._params() if var is None else var, yc.device, S)
+    dec = _new_decisions(yc, T)
+    fm = torch.empty((B, S), dtype=torch.float32, device=yc.device)
+    surv = torch.empty((B, T, max(1, S // 8)), dtype=torch.uint8, device=yc.device)
+    ws = torch.empty(max(B * T * S * 4, 16), dtype=torch.uint8, device=yc.device)  # the logits' scratch
+    with _lib.on_device(yc.device):
+        rc = _lib.load().mvn_vnet_decode_surv_f32(_lib.ptr(yc), Ty, *[_lib.ptr(t) for t in w], _lib.ptr(dec), Ty, _lib.ptr(fm), _lib.ptr(surv),
+                                                  _lib.ptr(ws), ws.numel(), B, T, S, _lib.current_stream(yc.device))
+    _lib.check(rc, "mvn_vnet_decode_surv_f32")
+    bits = torch.zeros_like(yc)
+    bits[:, :T] = traceback(surv, fm)
+    return (bits, dec, fm, surv) if return_all else bits
+
+
+VNETDetector.viterbi_path = _vnet_viterbi_path
+
+
 class META_VNETDetector(nn.Module):
     """Functional ViterbiNet: weights arrive as var=[W1,b1,W2,b2,W3,b3] so MAML can differentiate
     through an inner step (meta_vnet_detector.py:11-47).  Owns no parameters."""

@@ -1571,6 +1571,42 @@ def test_va_viterbi_path_with_traceback(oracle, dev, L):
     assert err_path <= err_running and (err_path <= 2 if L <= 4 else 2 * err_path < err_running), (err_path, err_running)
 
 
+@pytest.mark.parametrize("S", [4, 16, 64])
+@pytest.mark.parametrize("B,T", [(9, 136), (70, 200), (5, 33)])
+def test_vnet_viterbi_path_with_traceback(oracle, dev, S, B, T):
+    """VNETDetector.viterbi_path (mvn_vnet_decode_surv_f32 + mvn_traceback_f32): ViterbiNet with survivor-path traceback.  Its running
+    decisions and final metrics are forward(y,'val')'s; the survivors are the oracle's over the costs -logit of the oracle's (= the
+    reference's) logits; the traced-back path is the oracle's traceback.  16 states with T % 4 == 0: sweep16_quad_kernel<1, true, true>."""
+    rng = np.random.RandomState(S + B + T)
+    w = _rand_weights(S, rng, scale=2.0)
+    y = rng.normal(0, 2, (B, T)).astype(np.float32)
+    det = _vnet_with(w, S, T, dev)
+    yt = torch.tensor(y, device=dev)
+    bits, dec, fm, surv = det.viterbi_path(yt, return_all=True)
+    assert torch.equal(dec, det(yt, "val"))
+    _, rlg, rfm0 = oracle.vnet_decode(y, w, want_logits=True, want_final=True)
+    rdec, rfm, rsurv = oracle.acs_sweep_surv(-rlg)
+    rbits, _ = oracle.traceback(rsurv, rfm)
+    assert np.array_equal(rfm, rfm0)
+    assert np.array_equal(_np(dec), rdec) and np.array_equal(_np(fm), rfm) and np.array_equal(_np(surv), rsurv)
+    assert np.array_equal(_np(bits), rbits)
+    assert torch.equal(det.viterbi_path(yt), bits)
+
+
+def test_vnet_viterbi_path_errs_less_than_the_running_argmin(golden, dev):
+    """With the weights the reference trained (golden G7) on its own channel: the traced-back maximum-likelihood path through the
+    learned metrics sees all L observations of a symbol, the reference's running argmin L - 1 -- it makes fewer errors."""
+    g7 = golden("g7_by_word")
+    S, L, B, T = 16, 4, 400, 136
+    det = _vnet_with([g7[f"w{i}"] for i in range(6)], S, T, dev)
+    tx, y = mvn.synthetic_words(B, T, L, 10.0, 0.2, dev, seed=5)
+    bits, dec, _, _ = det.viterbi_path(y, return_all=True)
+    err_path = int((bits[:, :T - L] != tx[:, :T - L]).sum().item())
+    err_running = int((dec[:, :T - L] != tx[:, :T - L]).sum().item())
+    print(f"ViterbiNet, 10 dB, {B} x {T}: running argmin {err_running} errors, traceback {err_path}")
+    assert err_path < err_running, (err_path, err_running)
+
+
 @pytest.mark.parametrize("what", ["clean", "nan_y", "inf_y", "inf_prior", "nan_prior"])
 @pytest.mark.parametrize("B,T", [(40, 76), (17, 64), (300, 20)])
 def test_va_survivors_at_16_states_follow_torch_min(oracle, dev, monkeypatch, what, B, T):

@@ -46,3 +46,18 @@ for L, B in ((4, 10000), (8, 20000)):
     t0 = ms(lambda: va(y, "val", 10.0, 0.2))
     t1 = ms(lambda: va.viterbi_path(y, 10.0, 0.2))
     print(f"VA S {S:4d}  {B} x {T}: forward('val') {t0:7.3f} ms   viterbi_path (sweep with survivors + traceback) {t1:7.3f} ms ({t1 / t0:4.2f} x)", flush=True)
+
+import numpy as np  # noqa: E402
+
+g7 = np.load(os.path.join(ROOT, "tests", "golden", "g7_by_word.npz"))
+B, S, L = 10000, 16, 4
+det = mvn.VNETDetector(S, {"train": T, "val": T}).to(dev)
+with torch.no_grad():
+    for p, i in zip(det.parameters(), range(6)):
+        p.copy_(torch.tensor(g7[f"w{i}"]))
+tx, y = mvn.synthetic_words(B, T, L, 10.0, 0.2, dev, seed=5)
+t0 = ms(lambda: det(y, "val"))
+t1 = ms(lambda: det.viterbi_path(y))
+bits, dec = det.viterbi_path(y), det(y, "val")
+print(f"ViterbiNet S {S}  {B} x {T}: forward('val') {t0:7.3f} ms   viterbi_path (logits + sweep with survivors + traceback) {t1:7.3f} ms ({t1 / t0:4.2f} x)   "
+      f"bit errors at 10 dB: running argmin {int((dec[:, :T - L] != tx[:, :T - L]).sum())}, traceback {int((bits[:, :T - L] != tx[:, :T - L]).sum())}", flush=True)
