@@ -9,7 +9,8 @@
 //   out  : va_dec[B*T] | vnet_dec[B*T] | int64 va_counters[4] | int64 vnet_counters[4]
 //          and, at 16 states: int32 nerr[R] | enc[R*Tb] | theta[2*P]  -- one by-word block step for the first R = 4 words
 //          (mvn_vnet_byword_step_f32: Tb = 8 floor(T/8) symbols, RS with 2 parity bytes) and two trials of 5 full-word
-//          training iterations in one launch sequence (mvn_vnet_online_train_trials_f32, descriptors built here)
+//          training iterations in one launch sequence (mvn_vnet_online_train_trials_f32, descriptors built here), and the ViterbiNet
+//          decision with survivor-path traceback (mvn_vnet_decode_surv_f32 + mvn_traceback_f32)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -137,5 +138,27 @@ int main(int argc, char **argv) {
     fclose(o);
     printf("by-word step: bit errors of the first %d words %d %d %d %d; 2 trials x 5 training iterations done\n", R, nerr[0], nerr[1],
            nerr[2], nerr[3]);
+
+    // ---- ViterbiNet with survivor-path traceback (round 5): the sweep's survivors, then the maximum-likelihood path
+    uint8_t *dsurv = nullptr;
+    float *dfm = nullptr, *dbits = nullptr, *dlg = nullptr;
+    const size_t lg_bytes = (size_t)B * T * S * 4;
+    HIP_OK(hipMalloc(&dsurv, mvn_survivor_bytes(B, T, S)));
+    HIP_OK(hipMalloc(&dfm, (size_t)B * S * 4));
+    HIP_OK(hipMalloc(&dbits, (size_t)B * T * 4));
+    HIP_OK(hipMalloc(&dlg, lg_bytes));
+    MVN_OK_(mvn_vnet_decode_surv_f32(dy, T, dW1, db1, dW2, db2, dW3, db3, dvn, T, dfm, dsurv, dlg, lg_bytes, B, T, S, st));
+    MVN_OK_(mvn_traceback_f32(dsurv, dfm, dbits, T, nullptr, B, T, S, st));
+    HIP_OK(hipMemsetAsync(dc, 0, 64, st));
+    MVN_OK_(mvn_count_errors(dbits, T, dtx, T, nullptr, B, T, dc, st));
+    HIP_OK(hipStreamSynchronize(st));
+    std::vector<float> path((size_t)B * T);
+    HIP_OK(hipMemcpy(path.data(), dbits, path.size() * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(c, dc, 32, hipMemcpyDeviceToHost));
+    o = fopen(argv[2], "ab");
+    if (!o) { perror("open out"); return 1; }
+    fwrite(path.data(), 4, path.size(), o);
+    fclose(o);
+    printf("VNET with traceback: bit errors %lld / %lld\n", (long long)c[0], (long long)c[1]);
     return 0;
 }

@@ -1202,7 +1202,11 @@ def test_c_abi_demo(oracle, dev, tmp_path):
     tail = raw[2 * B * T * 4 + 64:]
     nerr = tail[:R * 4].view(np.int32)
     enc = tail[R * 4: R * 4 + R * Tb * 4].view(np.float32).reshape(R, Tb)
-    theta = tail[R * 4 + R * Tb * 4:].view(np.float32).reshape(2, P)
+    theta = tail[R * 4 + R * Tb * 4: R * 4 + R * Tb * 4 + 2 * P * 4].view(np.float32).reshape(2, P)
+    path = tail[R * 4 + R * Tb * 4 + 2 * P * 4:].view(np.float32).reshape(B, T)  # ViterbiNet with traceback (the demo's last call)
+    _, rlg = oracle.vnet_decode(y, w, want_logits=True)
+    _, rfm, rsurv = oracle.acs_sweep_surv(-rlg)
+    assert np.array_equal(path, oracle.traceback(rsurv, rfm)[0]) and "VNET with traceback" in out.stdout
     yt, txt = torch.tensor(y, device=dev), torch.tensor(tx, device=dev)
     det = _vnet_with(w, S, Tb, dev)
     dec = det(yt[:R, :Tb].contiguous(), "val")
