@@ -85,10 +85,13 @@ int mvn_acs_sweep_f32(const float *cost, float *dec, int64_t dec_ld, float *fina
  * The ViterbiNet detector with survivors (round 5): mvn_vnet_decode_f32's decisions and final metrics -- the same bits -- plus the
  * survivor planes of its sweep (branch cost = -logit, python_code/detectors/VNET/vnet_detector.py:57; acs_block's second return value,
  * utils/trellis_utils.py:30), so that mvn_traceback_f32 yields the maximum-likelihood path through the learned branch metrics -- the
- * textbook ViterbiNet decision, where the reference decides from a running argmin.  Runs the two-kernel route: the logits of as
- * many blocks as fit `workspace` (at least T*S*4 bytes, 16-byte aligned; B*T*S*4 for one pass), then the survivor sweep over them.
+ * textbook ViterbiNet decision, where the reference decides from a running argmin.  16 states, T % 4 == 0, 8-byte-aligned surv,
+ * 128-byte-aligned workspace: the fused detector itself (vnet16_dealt_kernel<false, true>: survivors out of its decision pass, no
+ * logits in HBM).  Otherwise the two-kernel route: the logits of as many blocks as fit `workspace` (at least T*S*4 bytes, 16-byte
+ * aligned), then the survivor sweep over them.  mvn_vnet_surv_workspace_bytes: what one pass wants (hand-off lines / B*T*S*4).
  *   surv [B, T, max(1, S/8)] as for mvn_acs_sweep_surv_f32.
  */
+size_t mvn_vnet_surv_workspace_bytes(int64_t B, int32_t T, int32_t S);
 int mvn_vnet_decode_surv_f32(const float *y, int64_t y_ld, const float *W1, const float *b1, const float *W2, const float *b2,
                              const float *W3, const float *b3, float *dec, int64_t dec_ld, float *final_metric, uint8_t *surv,
                              void *workspace, size_t workspace_bytes, int64_t B, int32_t T, int32_t S, mvn_stream_t stream);

@@ -25,6 +25,7 @@ SIGNATURES = {
     "mvn_acs_sweep_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
     "mvn_survivor_bytes": (ctypes.c_size_t, [_i64, _i32, _i32]),
     "mvn_acs_sweep_surv_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "mvn_vnet_surv_workspace_bytes": (ctypes.c_size_t, [_i64, _i32, _i32]),
     "mvn_vnet_decode_surv_f32": (ctypes.c_int, [_vp, _i64] + [_vp] * 6 + [_vp, _i64, _vp, _vp, _vp, ctypes.c_size_t, _i64, _i32, _i32, _vp]),
     "mvn_va_decode_surv_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp]),
     "mvn_traceback_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),

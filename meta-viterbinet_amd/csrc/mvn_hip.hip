@@ -714,9 +714,9 @@ struct DealtPlan {
     int groups, ring;
     int rings() const { return groups * (kDealtWaves / ring); }
 };
-DealtPlan dealt_plan(int64_t B, int T) {
+DealtPlan dealt_plan(int64_t B, int T, bool with_coop = true) {  // with_coop = false: the survivor form, which the cooperative kernel does not have
     DealtPlan p = {0, kDealtWaves};
-    if (sw(SW_DEALT) == '0' || fusedn_tiles() != 2 || coop_selected(B, T)) return p;
+    if (sw(SW_DEALT) == '0' || fusedn_tiles() != 2 || (with_coop && coop_selected(B, T))) return p;
     const int64_t units = ((int64_t)T + kDealtUnit - 1) / kDealtUnit;
     if (B < 1 || B * units >= ((int64_t)1 << 31)) return p;
     const int cus = current_device_cus();
@@ -760,11 +760,11 @@ int launch_vnet16_fused(const float *y, int64_t y_ld, const float *W1, const flo
         if (logits_out)
             hipLaunchKernelGGL((vnet16_dealt_kernel<true>), dim3((unsigned)dp.groups), dim3(64 * kDealtWaves), 0, st, y, y_ld, W1, b1, W2, b2,
                                W3, b3, dec, dec_ld, logits_out, final_metric, (int)B, T, tx, tx_ld, K, row_mask, counters, (float *)workspace,
-                               dp.groups, dp.ring, dealt_spin_limit(), dealt_skip_ring(), nonce);
+                               dp.groups, dp.ring, dealt_spin_limit(), dealt_skip_ring(), nonce, (unsigned char *)nullptr);
         else
             hipLaunchKernelGGL((vnet16_dealt_kernel<false>), dim3((unsigned)dp.groups), dim3(64 * kDealtWaves), 0, st, y, y_ld, W1, b1, W2, b2,
                                W3, b3, dec, dec_ld, logits_out, final_metric, (int)B, T, tx, tx_ld, K, row_mask, counters, (float *)workspace,
-                               dp.groups, dp.ring, dealt_spin_limit(), dealt_skip_ring(), nonce);
+                               dp.groups, dp.ring, dealt_spin_limit(), dealt_skip_ring(), nonce, (unsigned char *)nullptr);
         if (tx) hipLaunchKernelGGL(count_totals_kernel, dim3(1), dim3(1024), 0, st, row_mask, B, K, counters);
         return (int)hipGetLastError();
     }
@@ -1235,6 +1235,29 @@ int mvn_va_decode_surv_f32(const float *y, int64_t y_ld, const float *state_prio
     return launch_sweep_surv<MODE_VA>(y, y_ld, state_priors, Bp, dec, dec_ld, final_metric, surv, B, T, S, (hipStream_t)stream);
 }
 
+// ViterbiNet with survivors on the dealt kernel (16 states): no logits in HBM.  -1: not served (the caller takes the two-kernel route)
+int launch_vnet16_dealt_surv(const float *y, int64_t y_ld, const float *W1, const float *b1, const float *W2, const float *b2,
+                             const float *W3, const float *b3, float *dec, int64_t dec_ld, float *final_metric, unsigned char *surv,
+                             void *workspace, size_t workspace_bytes, int64_t B, int T, hipStream_t st) {
+    if (unfused_forced() || (T & 3) || (reinterpret_cast<uintptr_t>(surv) & 7) || (reinterpret_cast<uintptr_t>(workspace) & 127)) return -1;
+    const DealtPlan dp = dealt_plan(B, T, false);
+    if (!dp.groups || workspace_bytes < dealt_workspace_bytes(dp.rings())) return -1;
+    hipLaunchKernelGGL((vnet16_dealt_kernel<false, true>), dim3((unsigned)dp.groups), dim3(64 * kDealtWaves), 0, st, y, y_ld, W1, b1, W2, b2,
+                       W3, b3, dec, dec_ld, (float *)nullptr, final_metric, (int)B, T, (const float *)nullptr, (int64_t)0, 0,
+                       (const unsigned char *)nullptr, (unsigned long long *)nullptr, (float *)workspace, dp.groups, dp.ring, dealt_spin_limit(),
+                       dealt_skip_ring(), dealt_nonce(), surv);
+    return (int)hipGetLastError();
+}
+
+size_t mvn_vnet_surv_workspace_bytes(int64_t B, int32_t T, int32_t S) {
+    if (B <= 0 || T <= 0 || !valid_states(S)) return 0;
+    if (S == 16 && !unfused_forced() && !(T & 3)) {
+        const DealtPlan dp = dealt_plan(B, T, false);
+        if (dp.groups) return dealt_workspace_bytes(dp.rings());  // the fused detector: hand-off lines only
+    }
+    return (size_t)B * (size_t)T * (size_t)S * sizeof(float);  // the logits of the two-kernel route
+}
+
 int mvn_vnet_decode_surv_f32(const float *y, int64_t y_ld, const float *W1, const float *b1, const float *W2, const float *b2,
                              const float *W3, const float *b3, float *dec, int64_t dec_ld, float *final_metric, uint8_t *surv,
                              void *workspace, size_t workspace_bytes, int64_t B, int32_t T, int32_t S, mvn_stream_t stream) {
@@ -1245,6 +1268,10 @@ int mvn_vnet_decode_surv_f32(const float *y, int64_t y_ld, const float *W1, cons
     // the logits of a slice of blocks in the workspace (mlp_kernel: the reference's logits bit for bit), then the sweep over them
     // with branch cost -logit (vnet_detector.py:57) and the survivors kept; torch.min's rule inside the sweeps (odd costs)
     hipStream_t st = (hipStream_t)stream;
+    if (S == 16) {  // the fused detector itself (vnet16_dealt_kernel<false, true>: survivors out of its decision pass), when it serves the call
+        const int rf = launch_vnet16_dealt_surv(y, y_ld, W1, b1, W2, b2, W3, b3, dec, dec_ld, final_metric, surv, workspace, workspace_bytes, B, T, st);
+        if (rf >= 0) return rf;
+    }
     const size_t per_block = (size_t)T * (size_t)S * sizeof(float);
     int64_t slice = (int64_t)(workspace_bytes / per_block);
     if (slice < 1 || (reinterpret_cast<uintptr_t>(workspace) & 15)) return MVN_E_WORKSPACE;

@@ -294,7 +294,8 @@ def _vnet_viterbi_path(self, y: torch.Tensor, return_all: bool = False, var=None
     dec = _new_decisions(yc, T)
     fm = torch.empty((B, S), dtype=torch.float32, device=yc.device)
     surv = torch.empty((B, T, max(1, S // 8)), dtype=torch.uint8, device=yc.device)
-    ws = torch.empty(max(B * T * S * 4, 16), dtype=torch.uint8, device=yc.device)  # the logits' scratch
+    # hand-off lines of the fused detector (16 states) or the logits' scratch of the two-kernel route
+    ws = torch.empty(max(int(_lib.load().mvn_vnet_surv_workspace_bytes(B, T, S)), 16), dtype=torch.uint8, device=yc.device)
     with _lib.on_device(yc.device):
         rc = _lib.load().mvn_vnet_decode_surv_f32(_lib.ptr(yc), Ty, *[_lib.ptr(t) for t in w], _lib.ptr(dec), Ty, _lib.ptr(fm), _lib.ptr(surv),
                                                   _lib.ptr(ws), ws.numel(), B, T, S, _lib.current_stream(yc.device))

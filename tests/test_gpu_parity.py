@@ -1576,11 +1576,13 @@ def test_va_viterbi_path_with_traceback(oracle, dev, L):
 
 
 @pytest.mark.parametrize("S", [4, 16, 64])
-@pytest.mark.parametrize("B,T", [(9, 136), (70, 200), (5, 33)])
+@pytest.mark.parametrize("B,T", [(9, 136), (70, 200), (5, 33), (1300, 72), (7000, 40)])
 def test_vnet_viterbi_path_with_traceback(oracle, dev, S, B, T):
     """VNETDetector.viterbi_path (mvn_vnet_decode_surv_f32 + mvn_traceback_f32): ViterbiNet with survivor-path traceback.  Its running
     decisions and final metrics are forward(y,'val')'s; the survivors are the oracle's over the costs -logit of the oracle's (= the
-    reference's) logits; the traced-back path is the oracle's traceback.  16 states with T % 4 == 0: sweep16_quad_kernel<1, true, true>."""
+    reference's) logits; the traced-back path is the oracle's traceback.  16 states with T % 4 == 0: the fused detector itself
+    (vnet16_dealt_kernel<false, true>: rings of 8 / 4 / 1 waves here, ragged last units), no logits in HBM; otherwise the two-kernel route
+    (16 states: sweep16_quad_kernel<1, true, true>)."""
     rng = np.random.RandomState(S + B + T)
     w = _rand_weights(S, rng, scale=2.0)
     y = rng.normal(0, 2, (B, T)).astype(np.float32)
@@ -1595,6 +1597,16 @@ def test_vnet_viterbi_path_with_traceback(oracle, dev, S, B, T):
     assert np.array_equal(_np(dec), rdec) and np.array_equal(_np(fm), rfm) and np.array_equal(_np(surv), rsurv)
     assert np.array_equal(_np(bits), rbits)
     assert torch.equal(det.viterbi_path(yt), bits)
+    if S == 16:  # the two-kernel route gives the same planes
+        import os
+        os.environ["MVN_UNFUSED"] = "1"
+        try:
+            mvn._lib.reload_switches()
+            b2, d2, f2, s2 = det.viterbi_path(yt, return_all=True)
+        finally:
+            del os.environ["MVN_UNFUSED"]
+            mvn._lib.reload_switches()
+        assert torch.equal(s2, surv) and torch.equal(b2, bits) and torch.equal(d2, dec) and torch.equal(f2, fm)
 
 
 def test_vnet_viterbi_path_errs_less_than_the_running_argmin(golden, dev):

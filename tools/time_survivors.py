@@ -59,5 +59,5 @@ tx, y = mvn.synthetic_words(B, T, L, 10.0, 0.2, dev, seed=5)
 t0 = ms(lambda: det(y, "val"))
 t1 = ms(lambda: det.viterbi_path(y))
 bits, dec = det.viterbi_path(y), det(y, "val")
-print(f"ViterbiNet S {S}  {B} x {T}: forward('val') {t0:7.3f} ms   viterbi_path (logits + sweep with survivors + traceback) {t1:7.3f} ms ({t1 / t0:4.2f} x)   "
+print(f"ViterbiNet S {S}  {B} x {T}: forward('val') {t0:7.3f} ms   viterbi_path (fused detector with survivors + traceback) {t1:7.3f} ms ({t1 / t0:4.2f} x)   "
       f"bit errors at 10 dB: running argmin {int((dec[:, :T - L] != tx[:, :T - L]).sum())}, traceback {int((bits[:, :T - L] != tx[:, :T - L]).sum())}", flush=True)
