@@ -35,7 +35,7 @@ def rand_weights(S):
             ((1.5, (100, 1)), (1.0, (100,)), (0.3, (50, 100)), (0.3, (50,)), (0.4, (S, 50)), (0.3, (S,)))]
 
 
-n, t_end, kinds = 0, time.time() + budget, {"sweep": 0, "va": 0, "vnet": 0}
+n, t_end, kinds = 0, time.time() + budget, {"sweep": 0, "va": 0, "vnet": 0, "surv": 0}
 while time.time() < t_end:
     for k in ENV:
         os.environ.pop(k, None)
@@ -63,8 +63,46 @@ while time.time() < t_end:
         os.environ["MVN_UNFUSED"] = "1"
     if S != 16 and rng.rand() < 0.6:  # vnet_fused_ip_kernel<LB> at every S it serves / the two-kernel route
         os.environ["MVN_FUSED_IP"] = str(rng.choice(["0", "1"]))
-    kind = str(rng.choice(["sweep", "va", "vnet"]))
+    kind = str(rng.choice(["sweep", "va", "vnet", "surv"], p=[0.3, 0.3, 0.3, 0.1]))
     mvn._lib.reload_switches()
+    if kind == "surv":  # the survivor outputs + traceback of the three detectors (tuned 16-state kernels / the state-per-lane sweep)
+        which = str(rng.choice(["cost", "va", "vnet"]))
+        Ts = T if rng.rand() < 0.5 else 4 * ((T + 3) // 4)  # (T % 4 == 0: the tuned forms)
+        ys = rng.normal(0, 1.5, (B, Ts)).astype(np.float32)
+        yst = torch.tensor(ys, device=dev)
+        SB = max(1, S // 8)
+        dec_s, fm_s = torch.zeros(B, Ts, device=dev), torch.empty(B, S, device=dev)
+        sv = torch.zeros(B, Ts, SB, dtype=torch.uint8, device=dev)
+        with np.errstate(all="ignore"):
+            if which == "cost":
+                cost = np.round(rng.normal(0, 2, (B, Ts, S))).astype(np.float32) if rng.rand() < 0.5 else rng.normal(0, 2, (B, Ts, S)).astype(np.float32)
+                if rng.rand() < 0.2:
+                    cost[rng.randint(B), rng.randint(Ts), rng.randint(S)] = rng.choice([np.nan, np.inf, -np.inf])
+                ct = torch.tensor(cost, device=dev)
+                rc = lib.mvn_acs_sweep_surv_f32(ptr(ct), ptr(dec_s), Ts, ptr(fm_s), ptr(sv), B, Ts, S, st)
+            elif which == "va":
+                pri = rng.normal(0, 1, (1, S)).astype(np.float32)
+                cost = oracle.va_costs(ys, pri)
+                pt = torch.tensor(pri, device=dev)
+                rc = lib.mvn_va_decode_surv_f32(ptr(yst), Ts, ptr(pt), 1, ptr(dec_s), Ts, ptr(fm_s), ptr(sv), B, Ts, S, st)
+            else:
+                w = rand_weights(S)
+                cost = -oracle.vnet_decode(ys, w, want_logits=True)[1]
+                wt = [torch.tensor(a, device=dev) for a in w]
+                nb = int(lib.mvn_vnet_surv_workspace_bytes(B, Ts, S))
+                wsb = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+                rc = lib.mvn_vnet_decode_surv_f32(ptr(yst), Ts, *[ptr(a) for a in wt], ptr(dec_s), Ts, ptr(fm_s), ptr(sv), ptr(wsb), wsb.numel(),
+                                                  B, Ts, S, st)
+            rdec_s, rfm_s, rsv = oracle.acs_sweep_surv(cost)
+            rbits = oracle.traceback(rsv, rfm_s)[0]
+        assert rc == 0, (rc, which, S, B, Ts)
+        tag = f"surv/{which} S={S} B={B} T={Ts} env={ {k: os.environ[k] for k in ENV if k in os.environ} }"
+        assert np.array_equal(dec_s.cpu().numpy(), rdec_s) and np.array_equal(fm_s.cpu().numpy(), rfm_s, equal_nan=True), tag
+        assert np.array_equal(sv.cpu().numpy(), rsv), tag
+        assert np.array_equal(mvn.traceback(sv, fm_s).cpu().numpy(), rbits), tag
+        n += 1
+        kinds[kind] += 1
+        continue
     y = rng.normal(0, 1.5, (B, T)).astype(np.float32)
     if rng.rand() < 0.15:
         y[rng.randint(B), rng.randint(T)] = rng.choice([np.nan, np.inf, -np.inf])
