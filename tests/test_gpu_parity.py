@@ -267,7 +267,7 @@ def test_vnet_fused_ip_and_two_kernel_routes(oracle, dev, monkeypatch, S, B, T):
     rdec, rfm = oracle.vnet_decode(y, w, want_final=True)
     lib, st = mvn._lib.load(), mvn._lib.current_stream(dev)
     name = ctypes.create_string_buffer(96)
-    monkeypatch.setenv("MVN_FUSED_IP", "1")  # (128 and 256 states take the fused kernel on request only: the two-kernel route is faster there)
+    monkeypatch.setenv("MVN_FUSED_IP", "1")  # (pinned: small batches and 256 states take the two-kernel route by default)
     for unfused in ("0", "1"):
         monkeypatch.setenv("MVN_UNFUSED", unfused)
         assert lib.mvn_vnet_decode_kernel_name(B, T, S, 0, name, 96) == 0
